@@ -1,0 +1,210 @@
+// Forward-mode dual numbers for the gfx950 kernels (device only).
+//
+// Roles of the reference types (feos_torch/dual.py, feos_torch/dual_torch.py):
+//   D2<T>      value + 1st + 2nd derivative along ONE direction     (Dual3, dual.py:5-78)
+//   DN<T,N>    value + N first derivatives                          (parameter tangents; what
+//              torch reverse mode delivers in the reference is delivered forward here)
+//   HD<T,N>    value, eps1[N], eps2, eps1eps2[N]                     (DualTensor, dual_torch.py:4-158)
+// All are plain aggregates living in VGPRs; every loop over N is fully unrolled.  The types
+// nest (D2<DN<double,3>> = d/drho, d2/drho2 and their parameter tangents) and mix with plain
+// double on either side so model code is written once (pure_model.hpp, mix_model.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#define PCS_DEV __device__ __forceinline__
+
+namespace pcs {
+
+// ---- plain-double shims so generic code can call the same names ------------------------
+PCS_DEV double re(double x) { return x; }
+PCS_DEV double d_exp(double x) { return exp(x); }
+PCS_DEV double d_log(double x) { return log(x); }
+PCS_DEV double d_sqrt(double x) { return sqrt(x); }
+PCS_DEV double d_cbrt(double x) { return cbrt(x); }
+PCS_DEV double d_recip(double x) { return 1.0 / x; }
+
+// =========================================================================================
+// D2<T>
+// =========================================================================================
+template <class T>
+struct D2 {
+    T v, d1, d2;
+    PCS_DEV D2() {}
+    PCS_DEV D2(double x) : v(x), d1(0.0), d2(0.0) {}
+    PCS_DEV D2(const T& a, const T& b, const T& c) : v(a), d1(b), d2(c) {}
+    // f(g): (f0, f1 g', f2 g'^2 + f1 g'')
+    PCS_DEV D2 chain(const T& f0, const T& f1, const T& f2) const { return D2(f0, f1 * d1, f2 * (d1 * d1) + f1 * d2); }
+};
+template <class T> struct is_dual { static constexpr bool value = false; };
+template <class T> struct is_dual<D2<T>> { static constexpr bool value = true; };
+
+template <class T> PCS_DEV double re(const D2<T>& a) { return re(a.v); }
+template <class T> PCS_DEV D2<T> operator+(const D2<T>& a, const D2<T>& b) { return D2<T>(a.v + b.v, a.d1 + b.d1, a.d2 + b.d2); }
+template <class T> PCS_DEV D2<T> operator-(const D2<T>& a, const D2<T>& b) { return D2<T>(a.v - b.v, a.d1 - b.d1, a.d2 - b.d2); }
+template <class T> PCS_DEV D2<T> operator-(const D2<T>& a) { return D2<T>(-a.v, -a.d1, -a.d2); }
+template <class T> PCS_DEV D2<T> operator*(const D2<T>& a, const D2<T>& b) {
+    return D2<T>(a.v * b.v, a.d1 * b.v + a.v * b.d1, a.d2 * b.v + 2.0 * (a.d1 * b.d1) + a.v * b.d2);
+}
+// scalar (double) on either side
+template <class T> PCS_DEV D2<T> operator+(const D2<T>& a, double b) { return D2<T>(a.v + b, a.d1, a.d2); }
+template <class T> PCS_DEV D2<T> operator+(double b, const D2<T>& a) { return D2<T>(a.v + b, a.d1, a.d2); }
+template <class T> PCS_DEV D2<T> operator-(const D2<T>& a, double b) { return D2<T>(a.v - b, a.d1, a.d2); }
+template <class T> PCS_DEV D2<T> operator-(double b, const D2<T>& a) { return D2<T>(b - a.v, -a.d1, -a.d2); }
+template <class T> PCS_DEV D2<T> operator*(const D2<T>& a, double b) { return D2<T>(a.v * b, a.d1 * b, a.d2 * b); }
+template <class T> PCS_DEV D2<T> operator*(double b, const D2<T>& a) { return D2<T>(a.v * b, a.d1 * b, a.d2 * b); }
+template <class T> PCS_DEV D2<T> d_recip(const D2<T>& a) {
+    T r = d_recip(a.v);
+    T r2 = r * r;
+    return a.chain(r, -r2, 2.0 * (r2 * r));
+}
+template <class T> PCS_DEV D2<T> operator/(const D2<T>& a, const D2<T>& b) { return a * d_recip(b); }
+template <class T> PCS_DEV D2<T> operator/(const D2<T>& a, double b) { double r = 1.0 / b; return a * r; }
+template <class T> PCS_DEV D2<T> operator/(double b, const D2<T>& a) { return d_recip(a) * b; }
+template <class T> PCS_DEV D2<T> d_log(const D2<T>& a) { T r = d_recip(a.v); return a.chain(d_log(a.v), r, -(r * r)); }
+template <class T> PCS_DEV D2<T> d_exp(const D2<T>& a) { T e = d_exp(a.v); return a.chain(e, e, e); }
+template <class T> PCS_DEV D2<T> d_sqrt(const D2<T>& a) {
+    T s = d_sqrt(a.v);
+    T h = 0.5 * d_recip(s);              // 1/(2 sqrt x)
+    return a.chain(s, h, -(h * d_recip(a.v)) * 0.5);  // f'' = -1/(4 x sqrt x)
+}
+
+// D2<T> (x) T for a dual component type T (e.g. D2<DN<double,2>> with DN<double,2> coefficients)
+#define PCS_IFDUAL(T) std::enable_if_t<!std::is_same<T, double>::value, int> = 0
+template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator*(const D2<T>& a, const T& b) { return D2<T>(a.v * b, a.d1 * b, a.d2 * b); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator*(const T& b, const D2<T>& a) { return D2<T>(a.v * b, a.d1 * b, a.d2 * b); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator+(const D2<T>& a, const T& b) { return D2<T>(a.v + b, a.d1, a.d2); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator+(const T& b, const D2<T>& a) { return D2<T>(a.v + b, a.d1, a.d2); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator-(const D2<T>& a, const T& b) { return D2<T>(a.v - b, a.d1, a.d2); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator-(const T& b, const D2<T>& a) { return D2<T>(b - a.v, -a.d1, -a.d2); }
+
+// =========================================================================================
+// DN<T,N>
+// =========================================================================================
+template <class T, int N>
+struct DN {
+    T v;
+    T e[N];
+    PCS_DEV DN() {}
+    PCS_DEV DN(double x) : v(x) {
+#pragma unroll
+        for (int i = 0; i < N; i++) e[i] = T(0.0);
+    }
+    PCS_DEV DN chain(const T& f0, const T& f1) const {
+        DN r;
+        r.v = f0;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.e[i] = f1 * e[i];
+        return r;
+    }
+};
+template <class T, int N> struct is_dual<DN<T, N>> { static constexpr bool value = true; };
+template <class T, int N> PCS_DEV double re(const DN<T, N>& a) { return re(a.v); }
+#define PCS_DN_LOOP _Pragma("unroll") for (int i = 0; i < N; i++)
+template <class T, int N> PCS_DEV DN<T, N> operator+(const DN<T, N>& a, const DN<T, N>& b) { DN<T, N> r; r.v = a.v + b.v; PCS_DN_LOOP r.e[i] = a.e[i] + b.e[i]; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator-(const DN<T, N>& a, const DN<T, N>& b) { DN<T, N> r; r.v = a.v - b.v; PCS_DN_LOOP r.e[i] = a.e[i] - b.e[i]; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator-(const DN<T, N>& a) { DN<T, N> r; r.v = -a.v; PCS_DN_LOOP r.e[i] = -a.e[i]; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator*(const DN<T, N>& a, const DN<T, N>& b) { DN<T, N> r; r.v = a.v * b.v; PCS_DN_LOOP r.e[i] = a.e[i] * b.v + a.v * b.e[i]; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator+(const DN<T, N>& a, double b) { DN<T, N> r = a; r.v = a.v + b; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator+(double b, const DN<T, N>& a) { DN<T, N> r = a; r.v = a.v + b; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator-(const DN<T, N>& a, double b) { DN<T, N> r = a; r.v = a.v - b; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator-(double b, const DN<T, N>& a) { DN<T, N> r; r.v = b - a.v; PCS_DN_LOOP r.e[i] = -a.e[i]; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator*(const DN<T, N>& a, double b) { DN<T, N> r; r.v = a.v * b; PCS_DN_LOOP r.e[i] = a.e[i] * b; return r; }
+template <class T, int N> PCS_DEV DN<T, N> operator*(double b, const DN<T, N>& a) { return a * b; }
+template <class T, int N> PCS_DEV DN<T, N> d_recip(const DN<T, N>& a) { T r = d_recip(a.v); return a.chain(r, -(r * r)); }
+template <class T, int N> PCS_DEV DN<T, N> operator/(const DN<T, N>& a, const DN<T, N>& b) { return a * d_recip(b); }
+template <class T, int N> PCS_DEV DN<T, N> operator/(const DN<T, N>& a, double b) { double r = 1.0 / b; return a * r; }
+template <class T, int N> PCS_DEV DN<T, N> operator/(double b, const DN<T, N>& a) { return d_recip(a) * b; }
+template <class T, int N> PCS_DEV DN<T, N> d_log(const DN<T, N>& a) { return a.chain(d_log(a.v), d_recip(a.v)); }
+template <class T, int N> PCS_DEV DN<T, N> d_exp(const DN<T, N>& a) { T e = d_exp(a.v); return a.chain(e, e); }
+template <class T, int N> PCS_DEV DN<T, N> d_sqrt(const DN<T, N>& a) { T s = d_sqrt(a.v); return a.chain(s, 0.5 * d_recip(s)); }
+template <class T, int N> PCS_DEV DN<T, N> d_cbrt(const DN<T, N>& a) { T s = d_cbrt(a.v); return a.chain(s, s * d_recip(a.v) * (1.0 / 3.0)); }
+
+// =========================================================================================
+// HD<T,N>: hyper-dual with N "eps1" directions and one "eps2" direction
+// =========================================================================================
+template <class T, int N>
+struct HD {
+    T v;
+    T e1[N];
+    T e2;
+    T e12[N];
+    PCS_DEV HD() {}
+    PCS_DEV HD(double x) : v(x), e2(0.0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) { e1[i] = T(0.0); e12[i] = T(0.0); }
+    }
+    PCS_DEV HD chain(const T& f0, const T& f1, const T& f2) const {
+        HD r;
+        r.v = f0;
+        r.e2 = f1 * e2;
+        T f2e2 = f2 * e2;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            r.e1[i] = f1 * e1[i];
+            r.e12[i] = f1 * e12[i] + f2e2 * e1[i];
+        }
+        return r;
+    }
+};
+template <class T, int N> struct is_dual<HD<T, N>> { static constexpr bool value = true; };
+template <class T, int N> PCS_DEV double re(const HD<T, N>& a) { return re(a.v); }
+template <class T, int N> PCS_DEV HD<T, N> operator+(const HD<T, N>& a, const HD<T, N>& b) {
+    HD<T, N> r; r.v = a.v + b.v; r.e2 = a.e2 + b.e2;
+    PCS_DN_LOOP { r.e1[i] = a.e1[i] + b.e1[i]; r.e12[i] = a.e12[i] + b.e12[i]; }
+    return r;
+}
+template <class T, int N> PCS_DEV HD<T, N> operator-(const HD<T, N>& a, const HD<T, N>& b) {
+    HD<T, N> r; r.v = a.v - b.v; r.e2 = a.e2 - b.e2;
+    PCS_DN_LOOP { r.e1[i] = a.e1[i] - b.e1[i]; r.e12[i] = a.e12[i] - b.e12[i]; }
+    return r;
+}
+template <class T, int N> PCS_DEV HD<T, N> operator-(const HD<T, N>& a) {
+    HD<T, N> r; r.v = -a.v; r.e2 = -a.e2;
+    PCS_DN_LOOP { r.e1[i] = -a.e1[i]; r.e12[i] = -a.e12[i]; }
+    return r;
+}
+template <class T, int N> PCS_DEV HD<T, N> operator*(const HD<T, N>& a, const HD<T, N>& b) {
+    HD<T, N> r; r.v = a.v * b.v; r.e2 = a.v * b.e2 + b.v * a.e2;
+    PCS_DN_LOOP {
+        r.e1[i] = a.v * b.e1[i] + b.v * a.e1[i];
+        r.e12[i] = a.v * b.e12[i] + a.e1[i] * b.e2 + a.e2 * b.e1[i] + a.e12[i] * b.v;
+    }
+    return r;
+}
+template <class T, int N> PCS_DEV HD<T, N> operator+(const HD<T, N>& a, double b) { HD<T, N> r = a; r.v = a.v + b; return r; }
+template <class T, int N> PCS_DEV HD<T, N> operator+(double b, const HD<T, N>& a) { HD<T, N> r = a; r.v = a.v + b; return r; }
+template <class T, int N> PCS_DEV HD<T, N> operator-(const HD<T, N>& a, double b) { HD<T, N> r = a; r.v = a.v - b; return r; }
+template <class T, int N> PCS_DEV HD<T, N> operator-(double b, const HD<T, N>& a) { HD<T, N> r = -a; r.v = b - a.v; return r; }
+template <class T, int N> PCS_DEV HD<T, N> operator*(const HD<T, N>& a, double b) {
+    HD<T, N> r; r.v = a.v * b; r.e2 = a.e2 * b;
+    PCS_DN_LOOP { r.e1[i] = a.e1[i] * b; r.e12[i] = a.e12[i] * b; }
+    return r;
+}
+template <class T, int N> PCS_DEV HD<T, N> operator*(double b, const HD<T, N>& a) { return a * b; }
+template <class T, int N> PCS_DEV HD<T, N> d_recip(const HD<T, N>& a) { T r = d_recip(a.v); T r2 = r * r; return a.chain(r, -r2, 2.0 * (r2 * r)); }
+template <class T, int N> PCS_DEV HD<T, N> operator/(const HD<T, N>& a, const HD<T, N>& b) { return a * d_recip(b); }
+template <class T, int N> PCS_DEV HD<T, N> operator/(const HD<T, N>& a, double b) { double r = 1.0 / b; return a * r; }
+template <class T, int N> PCS_DEV HD<T, N> operator/(double b, const HD<T, N>& a) { return d_recip(a) * b; }
+template <class T, int N> PCS_DEV HD<T, N> d_log(const HD<T, N>& a) { T r = d_recip(a.v); return a.chain(d_log(a.v), r, -(r * r)); }
+template <class T, int N> PCS_DEV HD<T, N> d_exp(const HD<T, N>& a) { T e = d_exp(a.v); return a.chain(e, e, e); }
+template <class T, int N> PCS_DEV HD<T, N> d_sqrt(const HD<T, N>& a) {
+    T s = d_sqrt(a.v); T h = 0.5 * d_recip(s);
+    return a.chain(s, h, -(h * d_recip(a.v)) * 0.5);
+}
+template <class T, int N> PCS_DEV HD<T, N> d_cbrt(const HD<T, N>& a) {
+    T s = d_cbrt(a.v); T rx = d_recip(a.v); T f1 = s * rx * (1.0 / 3.0);
+    return a.chain(s, f1, f1 * rx * (-2.0 / 3.0));
+}
+
+// ---- lifting a parameter-type value P into a result type R -------------------------------
+// Model code is templated on <P, R>: P is the type of parameters / temperature-only
+// coefficients (double in the solvers, a dual in the gradient kernels), R the type of the
+// density (D2<double> in the solvers).  Either P is double, or P == R.
+template <class R, class P> struct Lift;
+template <class R> struct Lift<R, R> { static PCS_DEV const R& go(const R& p) { return p; } };
+template <class T> struct Lift<D2<T>, double> { static PCS_DEV D2<T> go(double p) { return D2<T>(p); } };
+template <class T, int N> struct Lift<DN<T, N>, double> { static PCS_DEV DN<T, N> go(double p) { return DN<T, N>(p); } };
+template <class T, int N> struct Lift<HD<T, N>, double> { static PCS_DEV HD<T, N> go(double p) { return HD<T, N>(p); } };
+
+}  // namespace pcs

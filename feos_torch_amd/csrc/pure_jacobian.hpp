@@ -1,0 +1,78 @@
+// Jacobians of the pure-component properties w.r.t. (m, sigma, epsilon_k, mu, kappa_ab,
+// epsilon_k_ab, na, nb, T, p) with the phase densities held fixed (device only).
+//
+// The reference obtains these by torch reverse mode through its Python tail
+// (feos_torch/pcsaft_pure.py:196-199, :212-215, :228-233): the densities arrive detached from
+// the Rust solver, so only the explicit dependence on parameters / T / p is differentiated.
+// Here the same partial derivatives are propagated FORWARD with DN<double,C> tangents, C
+// directions per pass, so that the whole state stays in registers (a single 10-direction pass
+// would need > 512 VGPRs for the coefficient set alone).
+#pragma once
+#include "pure_model.hpp"
+
+namespace pcs {
+
+constexpr int JAC_DIRS = 10;  // 8 parameters, T, p
+constexpr int JAC_CHUNK = 2;  // directions per pass
+
+// WHICH: 0 vapor_pressure [Pa], 1 liquid_density [kmol/m3], 2 equilibrium_liquid_density [kmol/m3]
+template <int WHICH>
+PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv, double rl, double g[JAC_DIRS]) {
+    typedef DN<double, JAC_CHUNK> G;
+    typedef D2<G> R;
+    constexpr int NPASS = (WHICH == 1) ? 5 : 5;  // direction 9 (p) is non-zero only for WHICH == 1
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; pass++) {
+        const int d0 = pass * JAC_CHUNK;
+        G gp[8], gT, gP;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            gp[k].v = par[k];
+#pragma unroll
+            for (int j = 0; j < JAC_CHUNK; j++) gp[k].e[j] = (d0 + j == k) ? 1.0 : 0.0;
+        }
+        gT.v = T;
+        gP.v = p_pa;
+#pragma unroll
+        for (int j = 0; j < JAC_CHUNK; j++) {
+            gT.e[j] = (d0 + j == 8) ? 1.0 : 0.0;
+            gP.e[j] = (d0 + j == 9) ? 1.0 : 0.0;
+        }
+        PureCoef<G> c;
+        pure_coef<G>(c, gp, gT, true);
+        G val;
+        if (WHICH == 0) {
+            // p = -(a_V/rho_V - a_L/rho_L + ln(rho_V/rho_L)) / (1/rho_V - 1/rho_L) * T * kB/A^3   (:212-215)
+            G a_l = pure_a<G, G>(c, G(rl));
+            G a_v = pure_a<G, G>(c, G(rv));
+            double inv_v = 1.0 / rv, inv_l = 1.0 / rl;
+            G num = a_v * inv_v - a_l * inv_l + log(rv * inv_l);
+            val = (num * (-1.0 / (inv_v - inv_l))) * gT * P_UNIT;
+        } else if (WHICH == 1) {
+            // rho - (p(rho) - p_spec)/dp  (:196-199)
+            R r = pure_a<G, R>(c, R(G(rl), G(1.0), G(0.0)));
+            G p = rl - r.v + rl * r.d1;
+            G dp = 1.0 + rl * r.d2;
+            G p_spec = gP / gT * (1.0 / P_UNIT);
+            val = (rl - (p - p_spec) / dp) * (1.0 / RHO_UNIT);
+        } else {
+            // (:228-233)
+            R r = pure_a<G, R>(c, R(G(rl), G(1.0), G(0.0)));
+            G p_l = rl - r.v + rl * r.d1;
+            G dp_l = 1.0 + rl * r.d2;
+            double inv_v = 1.0 / rv, inv_l = 1.0 / rl;
+            G a_l = r.v * inv_l;
+            G a_v = pure_a<G, G>(c, G(rv)) * inv_v;
+            G pp = (a_v - a_l + log(rv * inv_l)) * (-1.0 / (inv_v - inv_l));
+            val = (rl - (p_l - pp) / dp_l) * (1.0 / RHO_UNIT);
+        }
+#pragma unroll
+        for (int d = 0; d < JAC_DIRS; d++) {
+#pragma unroll
+            for (int j = 0; j < JAC_CHUNK; j++)
+                if (d == d0 + j) g[d] = val.e[j];
+        }
+    }
+}
+
+}  // namespace pcs

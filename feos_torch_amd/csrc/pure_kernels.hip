@@ -1,0 +1,347 @@
+// gfx950 kernels + C ABI for the pure-component PC-SAFT path (see include/pcsaft_hip.h).
+//
+// Launch shape: one state point per lane, 256-thread workgroups (4 waves), grid = ceil(n/256)
+// (>> 256 workgroups at the benchmark sizes, so all 8 XCDs fill; rows are independent, so the
+// round-robin workgroup->XCD placement needs no remapping — there is no shared tile to keep
+// in one L2).  HBM traffic is 81 B per state point against ~1e4 fp64 operations: the kernels
+// are fp64-VALU bound; memory handling only has to be coalesced, which it is:
+//   * the [n,8] AoS parameter rows of a workgroup (16 KB contiguous) are fetched with 16-byte
+//     per-lane loads and staged through LDS (72-byte padded rows, conflict-free ds_read_b64);
+//   * T, p and all outputs are SoA and accessed lane-contiguously.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/pcsaft_hip.h"
+#include "pure_solver.hpp"
+#include "pure_jacobian.hpp"
+
+using namespace pcs;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int RETRY_GRID = 1024;  // 64-thread workgroups of the robust pass
+constexpr int ROW_PAD = 9;  // doubles per staged row (8 + 1 pad): bank-conflict-free per-lane reads
+
+thread_local char g_err[256] = "";
+
+int fail(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return 1;
+}
+int fail_msg(const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return 2;
+}
+
+// Cooperative, coalesced load of the workgroup's parameter rows into LDS, then one row per lane.
+// Rows past n are clamped to row n-1 (their results are never stored).
+__device__ __forceinline__ void stage_params(const double* __restrict__ params, int64_t n, int64_t row0,
+                                             double* lds, double par[8]) {
+    const int t = threadIdx.x;
+    const double2* src = reinterpret_cast<const double2*>(params);
+    const int64_t last2 = n * 4 - 1;  // index of the last double2
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int idx2 = t + k * BLOCK;  // double2 index inside the block tile: row = idx2/4, col2 = idx2%4
+        int64_t g = row0 * 4 + idx2;
+        if (g > last2) g = last2 - 3 + (idx2 & 3);  // clamp to the same columns of row n-1
+        double2 v = src[g];
+        int r = idx2 >> 2, c2 = idx2 & 3;
+        lds[r * ROW_PAD + 2 * c2] = v.x;
+        lds[r * ROW_PAD + 2 * c2 + 1] = v.y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) par[k] = lds[t * ROW_PAD + k];
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: pure VLE, fast path.  Rows that need the robust initialisation are appended to
+// retry[1..]; retry[0] is the running count.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pure_vle(const double* __restrict__ params,
+                                                    const double* __restrict__ temp, int64_t n,
+                                                    double* __restrict__ p_sat, double* __restrict__ rho_eq,
+                                                    double* __restrict__ rho_vl, uint8_t* __restrict__ status,
+                                                    int32_t* __restrict__ iters, int32_t* __restrict__ retry) {
+    __shared__ double lds[BLOCK * ROW_PAD];
+    const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = row0 + threadIdx.x;
+    const bool live = i < n;
+    double par[8];
+    stage_params(params, n, row0, lds, par);
+    const double T = temp[live ? i : n - 1];
+
+    PureCoef<double> c;
+    pure_coef<double>(c, par, T, false);
+    VleResult r;
+    int st = vle_fast(c, r);
+
+    if (!live) return;
+    if (st == ST_OK) {
+        if (p_sat) p_sat[i] = r.p_star * T * P_UNIT;
+        if (rho_eq) rho_eq[i] = r.rho_l_new * (1.0 / RHO_UNIT);
+        if (rho_vl) {
+            rho_vl[2 * i] = r.rho_v;
+            rho_vl[2 * i + 1] = r.rho_l;
+        }
+        if (iters) iters[i] = r.iters;
+        status[i] = 0;
+    } else {
+        status[i] = 1;  // provisional; the robust pass overwrites it
+        int slot = atomicAdd(&retry[0], 1);
+        retry[1 + slot] = (int32_t)i;  // n < 2^31 checked on the host
+    }
+}
+
+// K1b: robust pass over the compacted retry list (grid-stride, count read on device: no host sync).
+__global__ __launch_bounds__(64) void k_pure_vle_robust(const double* __restrict__ params,
+                                                        const double* __restrict__ temp,
+                                                        double* __restrict__ p_sat, double* __restrict__ rho_eq,
+                                                        double* __restrict__ rho_vl, uint8_t* __restrict__ status,
+                                                        int32_t* __restrict__ iters,
+                                                        const int32_t* __restrict__ retry) {
+    const int count = retry[0];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const int64_t i = retry[1 + k];
+        double par[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) par[j] = params[8 * i + j];
+        const double T = temp[i];
+        PureCoef<double> c;
+        pure_coef<double>(c, par, T, false);
+        VleResult r;
+        int st = vle_robust(c, r);
+        if (st == ST_OK) {
+            if (p_sat) p_sat[i] = r.p_star * T * P_UNIT;
+            if (rho_eq) rho_eq[i] = r.rho_l_new * (1.0 / RHO_UNIT);
+            if (rho_vl) {
+                rho_vl[2 * i] = r.rho_v;
+                rho_vl[2 * i + 1] = r.rho_l;
+            }
+            if (iters) iters[i] = 1000 + r.iters;
+            status[i] = 0;
+        } else {
+            if (p_sat) p_sat[i] = 0.0;
+            if (rho_eq) rho_eq[i] = 0.0;
+            if (rho_vl) {
+                rho_vl[2 * i] = 0.0;
+                rho_vl[2 * i + 1] = 0.0;
+            }
+            if (iters) iters[i] = -1;
+            status[i] = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: liquid density at (T, p)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pure_liquid_density(const double* __restrict__ params,
+                                                               const double* __restrict__ temp,
+                                                               const double* __restrict__ pressure, int64_t n,
+                                                               double* __restrict__ rho_out,
+                                                               double* __restrict__ rho_root,
+                                                               uint8_t* __restrict__ status) {
+    __shared__ double lds[BLOCK * ROW_PAD];
+    const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = row0 + threadIdx.x;
+    const bool live = i < n;
+    double par[8];
+    stage_params(params, n, row0, lds, par);
+    const int64_t ii = live ? i : n - 1;
+    const double T = temp[ii];
+    const double p_red = pressure[ii] / (T * P_UNIT);  // pcsaft_pure.py:196
+
+    PureCoef<double> c;
+    pure_coef<double>(c, par, T, false);
+    double rho;
+    Eval last;
+    int st = liquid_newton(c, p_red, TOL_STEP, rho, last);
+    if (!live) return;
+    // `rho` already carries the final Newton update; the point it was taken at:
+    double root = rho + (last.p - p_red) / last.dp;
+    bool ok = (st == ST_OK);
+    if (rho_out) rho_out[i] = ok ? rho * (1.0 / RHO_UNIT) : 0.0;
+    if (rho_root) rho_root[i] = ok ? root : 0.0;
+    status[i] = ok ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// derivatives (a, p, dp) at given (T, rho)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pure_derivatives(const double* __restrict__ params,
+                                                            const double* __restrict__ temp,
+                                                            const double* __restrict__ rho_in, int64_t n,
+                                                            double* __restrict__ a, double* __restrict__ p,
+                                                            double* __restrict__ dp) {
+    __shared__ double lds[BLOCK * ROW_PAD];
+    const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = row0 + threadIdx.x;
+    const bool live = i < n;
+    double par[8];
+    stage_params(params, n, row0, lds, par);
+    const int64_t ii = live ? i : n - 1;
+    PureCoef<double> c;
+    pure_coef<double>(c, par, temp[ii], false);
+    Eval e = pure_eval(c, rho_in[ii]);
+    if (!live) return;
+    if (a) a[i] = e.a;
+    if (p) p[i] = e.p;
+    if (dp) dp[i] = e.dp;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: Jacobian of a property w.r.t. (8 parameters, T, p) at fixed densities
+// ------------------------------------------------------------------------------------------
+template <int WHICH>
+__global__ __launch_bounds__(BLOCK) void k_pure_jacobian(const double* __restrict__ params,
+                                                         const double* __restrict__ temp,
+                                                         const double* __restrict__ pressure,
+                                                         const double* __restrict__ rho_vl, int64_t n,
+                                                         double* __restrict__ jac) {
+    __shared__ double lds[BLOCK * ROW_PAD];
+    const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = row0 + threadIdx.x;
+    const bool live = i < n;
+    double par[8];
+    stage_params(params, n, row0, lds, par);
+    const int64_t ii = live ? i : n - 1;
+    const double T = temp[ii];
+    const double p_pa = (WHICH == 1) ? pressure[ii] : 0.0;
+    const double rv = rho_vl[2 * ii], rl = rho_vl[2 * ii + 1];
+    double g[10];
+    pure_jacobian<WHICH>(par, T, p_pa, rv, rl, g);
+    if (!live) return;
+    // a failed row carries zero densities -> NaNs; the caller masks by status
+#pragma unroll
+    for (int k = 0; k < 10; k++) jac[10 * i + k] = g[k];
+}
+
+hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int check_n(int64_t n) {
+    if (n < 0) return fail_msg("n must be >= 0");
+    if (n >= (int64_t)1 << 31) return fail_msg("n must be < 2^31 rows per call (shard larger batches)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcs_abi_version(void) { return 100; }
+
+const char* pcs_last_error(void) { return g_err; }
+
+int64_t pcs_workspace_bytes(int64_t n) { return (int64_t)sizeof(int32_t) * (n + 1); }
+
+// stage 1: zero the retry counter and run the fast kernel over all rows
+static int launch_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                           double* rho_vl, uint8_t* status, int32_t* iters, int32_t* retry, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return fail("hipMemsetAsync", e);
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_pure_vle, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
+                       iters, retry);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_vle launch", e);
+    return 0;
+}
+
+// stage 2: robust pass, small fixed grid; the retry count is read on the device (no host sync)
+static int launch_vle_retry(const double* params, const double* temp, double* p_sat, double* rho_eq,
+                            double* rho_vl, uint8_t* status, int32_t* iters, const int32_t* retry, hipStream_t s) {
+    hipLaunchKernelGGL(k_pure_vle_robust, dim3(RETRY_GRID), dim3(64), 0, s, params, temp, p_sat, rho_eq, rho_vl,
+                       status, iters, retry);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_vle_robust launch", e);
+    return 0;
+}
+
+static int vle_args_ok(const double* params, const double* temp, int64_t n, const uint8_t* status,
+                       const void* workspace) {
+    if (int e = check_n(n)) return e;
+    if (n > 0 && (!params || !temp || !status || !workspace)) return fail_msg("pcs_pure_vle: null required pointer");
+    return 0;
+}
+
+int pcs_pure_vle(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                 double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream) {
+    g_err[0] = 0;
+    if (int e = vle_args_ok(params, temp, n, status, workspace)) return e;
+    if (n == 0) return 0;
+    int32_t* retry = static_cast<int32_t*>(workspace);
+    if (int e = launch_vle_fast(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, as_stream(stream))) return e;
+    return launch_vle_retry(params, temp, p_sat, rho_eq, rho_vl, status, iters, retry, as_stream(stream));
+}
+
+int pcs_pure_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                      double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream) {
+    g_err[0] = 0;
+    if (int e = vle_args_ok(params, temp, n, status, workspace)) return e;
+    if (n == 0) return 0;
+    return launch_vle_fast(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, static_cast<int32_t*>(workspace),
+                           as_stream(stream));
+}
+
+int pcs_pure_vle_retry(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                       double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream) {
+    g_err[0] = 0;
+    if (int e = vle_args_ok(params, temp, n, status, workspace)) return e;
+    if (n == 0) return 0;
+    return launch_vle_retry(params, temp, p_sat, rho_eq, rho_vl, status, iters,
+                            static_cast<const int32_t*>(workspace), as_stream(stream));
+}
+
+int pcs_pure_liquid_density(const double* params, const double* temp, const double* pressure, int64_t n,
+                            double* rho_out, double* rho_root, uint8_t* status, void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !temp || !pressure || !status) return fail_msg("pcs_pure_liquid_density: null required pointer");
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_pure_liquid_density, dim3(grid), dim3(BLOCK), 0, as_stream(stream), params, temp, pressure,
+                       n, rho_out, rho_root, status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_liquid_density launch", e);
+    return 0;
+}
+
+int pcs_pure_derivatives(const double* params, const double* temp, const double* rho, int64_t n, double* a,
+                         double* p, double* dp, void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !temp || !rho) return fail_msg("pcs_pure_derivatives: null required pointer");
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_pure_derivatives, dim3(grid), dim3(BLOCK), 0, as_stream(stream), params, temp, rho, n, a, p,
+                       dp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_derivatives launch", e);
+    return 0;
+}
+
+int pcs_pure_jacobian(int which, const double* params, const double* temp, const double* pressure,
+                      const double* rho_vl, int64_t n, double* jac, void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !temp || !rho_vl || !jac) return fail_msg("pcs_pure_jacobian: null required pointer");
+    if (which == 1 && !pressure) return fail_msg("pcs_pure_jacobian: pressure required for liquid_density");
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipStream_t s = as_stream(stream);
+    switch (which) {
+        case 0: hipLaunchKernelGGL(k_pure_jacobian<0>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac); break;
+        case 1: hipLaunchKernelGGL(k_pure_jacobian<1>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac); break;
+        case 2: hipLaunchKernelGGL(k_pure_jacobian<2>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac); break;
+        default: return fail_msg("pcs_pure_jacobian: which must be 0, 1 or 2");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_jacobian launch", e);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// Pure-component PC-SAFT reduced residual Helmholtz energy density a(T, rho) [A^-3] for the
+// gfx950 kernels — the model of the reference's PcSaftPure.helmholtz_energy
+// (feos_torch/pcsaft_pure.py:106-178), re-derived for a one-state-point-per-lane kernel:
+//
+//   stage 1  pure_coef():  everything that depends on (parameters, T) only — segment diameter
+//            (:108), packing-fraction factor (:110), the 7+7 dispersion polynomial coefficients
+//            (:129-133), the 5+4 dipole coefficients (:146-154), prefactors and the
+//            association strength prefactor (:163-167).  Done ONCE per state point.
+//   stage 2  pure_a():     the density-dependent part, called inside the Newton loops.  Horner
+//            polynomials instead of the reference's power table (:115), one log for the chain
+//            term, and a cancellation-free form of the association site fractions (see below).
+//
+// P = type of parameters/coefficients (double in solvers, a dual in gradient kernels),
+// R = type of the density (D2<double> in solvers).  Either P is double or P == R.
+#pragma once
+#include "dual.hpp"
+#include "pcsaft_consts.hpp"
+
+namespace pcs {
+
+template <class P>
+struct PureCoef {
+    P m, mm1, ceta;    // m, m-1, eta = ceta * rho
+    P ai[7], bi[7];    // I1, I2 polynomial coefficients in eta
+    P kd1, kd2;        // disp = rho^2 (kd1 I1 + kd2 C1 I2)
+    P j1[5], j2[4];    // dipole pair / triplet polynomials with -pi/s3 resp. -4/3 pi^2 mu2t/s3 folded in
+    P qm;              // mu2t^2:  dipole = rho^2 qm J1^2 / (J1 - rho J2)
+    P da;              // (exp(eps_AB/T) - 1) sigma^3 kappa_AB
+    P na, nb;
+    bool polar, assoc;
+};
+
+// stage 1.  par = (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb)  (README.md:12)
+// for_gradient keeps terms whose VALUE vanishes but whose parameter derivative does not
+// (kappa_ab = 0 or epsilon_k_ab = 0 with sites present).
+template <class P>
+PCS_DEV void pure_coef(PureCoef<P>& c, const P* par, const P& T, bool for_gradient) {
+    const P& m = par[0];
+    const P& sigma = par[1];
+    const P& eps = par[2];
+    const P& mu = par[3];
+    P rT = d_recip(T);
+    P s3 = sigma * sigma * sigma;
+    P e = eps * rT;
+    P d = sigma * (1.0 - 0.12 * d_exp(-3.0 * e));  // :108
+    c.m = m;
+    c.mm1 = m - 1.0;
+    c.ceta = FRAC_PI_6 * (m * (d * d * d));  // :110
+    P rm = d_recip(m);
+    P m1 = c.mm1 * rm;
+    P m2 = (m - 2.0) * rm;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {  // :131-133
+        c.ai[i] = m1 * (m2 * A2[i] + A1[i]) + A0[i];
+        c.bi[i] = m1 * (m2 * B2[i] + B1[i]) + B0[i];
+    }
+    P pref = (-PI) * ((m * m) * (e * s3));  // :142
+    c.kd1 = 2.0 * pref;
+    c.kd2 = pref * (m * e);  // :141
+
+    // dipole (:145-160).  mu2 e s3 = mu^2 / (m s3 eps) * MU2_UNIT * (eps/T) * s3
+    c.polar = re(mu) != 0.0;
+    if (c.polar) {
+        P mu2t = (mu * mu) * (rm * rT) * MU2_UNIT;
+        bool clamp = re(m) > 2.0;  // :146
+        P md1 = clamp ? P(0.5) : m1;
+        P md2 = clamp ? P(0.0) : md1 * m2;
+        // phi2 = rho^2 (-pi/s3) J1, phi3 = rho^3 (-4/3 pi^2/s3) J2 (:158-159);
+        // dipole = phi2^2 mu2t^2 / (phi2 - phi3 mu2t) = rho^2 mu2t^2 J1'^2 / (J1' - rho J2')
+        // with J1' = (-pi/s3) J1 and J2' = (-4/3 pi^2 mu2t/s3) J2.
+        P rs3 = d_recip(s3);
+        P f2 = (-PI) * rs3;
+        P f3 = (-PI_SQ_43) * (rs3 * mu2t);
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            P a = AD[i][0] + md1 * AD[i][1] + md2 * AD[i][2];
+            if (i < 3) a = a + (BD[i][0] + md1 * BD[i][1] + md2 * BD[i][2]) * e;
+            c.j1[i] = a * f2;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) c.j2[i] = (CD[i][0] + md1 * CD[i][1] + md2 * CD[i][2]) * f3;
+        c.qm = mu2t * mu2t;
+    }
+
+    // association (:163-167)
+    c.na = par[6];
+    c.nb = par[7];
+    bool sites = (re(par[6]) != 0.0) || (re(par[7]) != 0.0);
+    c.da = (d_exp(par[5] * rT) - 1.0) * s3 * par[4];
+    c.assoc = sites && (for_gradient || re(c.da) != 0.0);
+}
+
+template <int N, class P, class R>
+PCS_DEV R horner(const P* coef, const R& x) {
+    R acc = x * coef[N - 1] + coef[N - 2];
+#pragma unroll
+    for (int i = N - 3; i >= 0; i--) acc = acc * x + coef[i];
+    return acc;
+}
+
+template <class R>
+PCS_DEV R site_term(const R& x) {  // ln x - x/2 + 1/2   (:176)
+    return d_log(x) - 0.5 * x + 0.5;
+}
+
+// stage 2: a(rho) at fixed coefficients
+template <class P, class R>
+PCS_DEV R pure_a(const PureCoef<P>& c, const R& rho) {
+    R eta = rho * c.ceta;
+    R eta2 = eta * eta;
+    R eta_m1 = d_recip(1.0 - eta);
+    R eta_m2 = eta_m1 * eta_m1;
+
+    // hard sphere (:118) + hard chain (:121-122)
+    R mrho = rho * c.m;
+    R hs = mrho * ((4.0 * eta - 3.0 * eta2) * eta_m2);
+    R g = (1.0 - 0.5 * eta) * (eta_m1 * eta_m2);
+    R hc = (rho * c.mm1) * d_log(g);
+
+    // dispersion (:125-142)
+    R I1 = horner<7>(c.ai, eta);
+    R I2 = horner<7>(c.bi, eta);
+    R eta_m4 = eta_m2 * eta_m2;
+    R t2 = eta_m1 * d_recip(2.0 - eta);
+    R poly = eta * (20.0 + eta * (-27.0 + eta * (12.0 - 2.0 * eta)));
+    R C1 = d_recip(1.0 + (eta * (8.0 - 2.0 * eta)) * eta_m4 * c.m - (poly * (t2 * t2)) * c.mm1);
+    R rho2 = rho * rho;
+    R a = hs - hc + rho2 * (I1 * c.kd1 + (C1 * I2) * c.kd2);
+
+    // dipoles (:145-160)
+    if (c.polar) {
+        R J1 = horner<5>(c.j1, eta);
+        R J2 = horner<4>(c.j2, eta);
+        a = a + (rho2 * c.qm) * ((J1 * J1) * d_recip(J1 - rho * J2));
+    }
+
+    // association (:163-176)
+    if (c.assoc) {
+        R k = eta * eta_m1;
+        R delta = ((1.0 + k * (1.5 + 0.5 * k)) * eta_m1) * c.da;
+        R rhoa = rho * c.na;
+        R rhob = rho * c.nb;
+        R t = (rhob - rhoa) * delta;
+        R aux = 1.0 - t;
+        R sq = d_sqrt(aux * aux + 4.0 * (rhob * delta));
+        // Site fractions.  As written in the reference, xa = 2/(sq+1+t), xb = 2/(sq+1-t); one of
+        // the two denominators cancels catastrophically when |t| >> 1 (strong association, low
+        // T: up to 8 digits lost in fp64).  (sq+1+t)(sq-1-t) = 4 rhoa delta and
+        // (sq+1-t)(sq-1+t) = 4 rhob delta give the algebraically identical conjugate forms.
+        R xa, xb;
+        double tr = re(t);
+        if (tr > 0.5) {
+            xa = 2.0 * d_recip(sq + 1.0 + t);
+            xb = (sq - 1.0 + t) * d_recip(2.0 * (rhob * delta));
+        } else if (tr < -0.5) {
+            xa = (sq - 1.0 - t) * d_recip(2.0 * (rhoa * delta));
+            xb = 2.0 * d_recip(sq + 1.0 - t);
+        } else {
+            xa = 2.0 * d_recip(sq + 1.0 + t);
+            xb = 2.0 * d_recip(sq + 1.0 - t);
+        }
+        a = a + rhoa * site_term(xa) + rhob * site_term(xb);
+    }
+    return a;
+}
+
+}  // namespace pcs

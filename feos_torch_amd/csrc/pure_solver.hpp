@@ -1,0 +1,272 @@
+// Per-lane solvers for the pure-component path (device only).
+//
+// What the reference delegates to the third-party feos crate (src/pcsaft.rs:91
+// PhaseEquilibrium::pure, :116-122 State::new_npt(.., Liquid)) is implemented here as
+// fixed-cap batched Newton iterations, one state point per lane:
+//
+//   * liquid density at given (T, p): Newton in rho from a liquid-like packing fraction,
+//     monotone from the high-density side where p(rho) is convex;
+//   * pure VLE at given T: both phase densities are driven towards the equal-area pressure
+//     p* = -(f_V - f_L)/(v_V - v_L),  f = a/rho + ln rho, by one Newton step each per
+//     iteration.  p* is exactly the reference's final formula (feos_torch/pcsaft_pure.py:214)
+//     and the liquid step is exactly its equilibrium-density formula (:232), so the values the
+//     reference computes AFTER the solve fall out of the last iteration for free.
+//
+// Loops are wave-uniform: every lane keeps a `done` flag and the loop exits on
+// __ballot(!done) == 0 (or the iteration cap).
+#pragma once
+#include "pure_model.hpp"
+
+namespace pcs {
+
+enum : int { ST_OK = 0, ST_FAILED = 1, ST_RETRY = 2 };
+
+struct Eval {
+    double a, p, dp;  // a, p = rho - a + rho a', dp/drho = 1 + rho a''   (pcsaft_pure.py:182)
+};
+
+PCS_DEV Eval pure_eval(const PureCoef<double>& c, double rho) {
+    D2<double> r = pure_a<double, D2<double>>(c, D2<double>(rho, 1.0, 0.0));
+    Eval e;
+    e.a = r.v;
+    e.p = rho - r.v + rho * r.d1;
+    e.dp = 1.0 + rho * r.d2;
+    return e;
+}
+
+// a'(rho) as well (residual chemical potential), used for the ideal-gas vapour estimate
+PCS_DEV Eval pure_eval_mu(const PureCoef<double>& c, double rho, double& mu_res) {
+    D2<double> r = pure_a<double, D2<double>>(c, D2<double>(rho, 1.0, 0.0));
+    Eval e;
+    e.a = r.v;
+    e.p = rho - r.v + rho * r.d1;
+    e.dp = 1.0 + rho * r.d2;
+    mu_res = r.d1;
+    return e;
+}
+
+constexpr int LIQ_MAX_IT = 40;
+constexpr int VLE_MAX_IT = 40;
+constexpr double ETA_START = 0.5;
+constexpr double TOL_STEP = 1e-10;  // relative Newton step at which a lane is converged
+
+// Newton for p(rho) = p_spec from the dense side.  Returns ST_OK with the converged density
+// (rho) and the LAST Newton update already applied (so rho is also the reference's final
+// formula rho - (p - p_spec)/dp of pcsaft_pure.py:198), ST_FAILED when the liquid branch has
+// no root at this pressure (iterate crossed the spinodal), or when the cap is hit.
+// `tol` is loose (1e-6) when used as an initialiser.
+PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, double& rho, Eval& last) {
+    rho = ETA_START / c.ceta;
+    bool done = false, fail = false;
+    for (int it = 0; it < LIQ_MAX_IT; it++) {
+        if (!done && !fail) {
+            Eval e = pure_eval(c, rho);
+            if (it == 0 && !(e.p > p_spec)) {
+                // very cold / very dense state: start further right (still eta < 0.74)
+                rho = 0.62 / c.ceta;
+                e = pure_eval(c, rho);
+            }
+            if (!(e.dp > 0.0) || !(e.p == e.p)) {
+                fail = true;
+            } else {
+                double step = (e.p - p_spec) / e.dp;
+                last = e;
+                double rho_new = rho - step;
+                if (!(rho_new > 0.0)) {
+                    fail = true;
+                } else {
+                    done = fabs(step) <= tol * rho;
+                    rho = rho_new;
+                }
+            }
+        }
+        if (__ballot(!done && !fail) == 0ull) break;
+    }
+    return (done && !fail) ? ST_OK : ST_FAILED;
+}
+
+struct VleResult {
+    double rho_v, rho_l;   // densities BEFORE the last Newton update (where p* was evaluated)
+    double rho_l_new;      // liquid density after the last update  (pcsaft_pure.py:232)
+    double p_star;         // equal-area pressure, reduced            (pcsaft_pure.py:214 / :231)
+    int iters;
+};
+
+// Fast path of the pure VLE: zero-pressure liquid + ideal-gas vapour initialisation, then the
+// coupled Newton.  ST_RETRY = this initialisation does not apply (near-critical temperature);
+// the robust kernel takes those rows.
+PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
+    double rl;
+    Eval el;
+    int st = liquid_newton(c, 0.0, 1e-3, rl, el);
+    bool active = (st == ST_OK);
+    double rv = 0.0;
+    if (active) {
+        double mu;
+        Eval e = pure_eval_mu(c, rl, mu);
+        if (!(e.dp > 0.0)) active = false;
+        rv = rl * exp(mu);  // ln rho_V = ln rho_L + a'(rho_L): ideal vapour at the liquid's fugacity
+        // non-ideal vapour estimates are left to the robust path
+        if (!(rv < 0.05 * rl)) active = false;
+    }
+    bool retry = !active;
+    bool done = false;
+    out.iters = 0;
+    for (int it = 0; it < VLE_MAX_IT; it++) {
+        if (active && !done) {
+            Eval l = pure_eval(c, rl);
+            Eval v = pure_eval(c, rv);
+            double inv_v = 1.0 / rv, inv_l = 1.0 / rl;
+            double p_star = -(v.a * inv_v - l.a * inv_l + log(rv * inv_l)) / (inv_v - inv_l);
+            double dl = -(l.p - p_star) / l.dp;
+            double dv = -(v.p - p_star) / v.dp;
+            bool ok = (l.dp > 0.0) && (v.dp > 0.0) && (p_star == p_star);
+            double rl_new = rl + dl, rv_new = rv + dv;
+            ok = ok && (rl_new > 0.0) && (rv_new > 0.0) && (rv_new < rl_new);
+            if (!ok) {
+                active = false;
+                retry = true;
+            } else {
+                out.rho_v = rv;
+                out.rho_l = rl;
+                out.rho_l_new = rl_new;
+                out.p_star = p_star;
+                out.iters = it + 1;
+                done = (fabs(dl) <= TOL_STEP * rl) && (fabs(dv) <= TOL_STEP * rv);
+                rl = rl_new;
+                rv = rv_new;
+            }
+        }
+        if (__ballot(active && !done) == 0ull) break;
+    }
+    if (done) return ST_OK;
+    return ST_RETRY;  // includes cap hit: let the robust path decide
+}
+
+// ---------------------------------------------------------------------------------------------
+// Robust path (rare rows: near-critical temperatures, strongly non-ideal vapour).  Lane-serial
+// bisections; no wave-uniform tricks needed because it runs on a compacted list of few rows.
+// ---------------------------------------------------------------------------------------------
+PCS_DEV double branch_solve(const PureCoef<double>& c, double p_spec, double lo, double hi, double rho) {
+    for (int it = 0; it < 100; it++) {
+        Eval e = pure_eval(c, rho);
+        if (e.p > p_spec) hi = rho; else lo = rho;
+        double rho_new = (e.dp > 0.0) ? rho - (e.p - p_spec) / e.dp : -1.0;
+        if (!(rho_new > lo && rho_new < hi)) rho_new = 0.5 * (lo + hi);
+        double diff = fabs(rho_new - rho);
+        rho = rho_new;
+        if (diff <= 1e-13 * rho) break;
+    }
+    return rho;
+}
+
+PCS_DEV double spinodal_bisect(const PureCoef<double>& c, double lo, double hi, bool dp_positive_at_lo) {
+    for (int it = 0; it < 50; it++) {
+        double mid = 0.5 * (lo + hi);
+        Eval e = pure_eval(c, mid);
+        if ((e.dp > 0.0) == dp_positive_at_lo) lo = mid; else hi = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
+PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
+    double rl, rv;
+    Eval el;
+    // 1. try the zero-pressure liquid with a tight tolerance and pull the vapour guess back
+    //    onto the stable vapour branch by halving
+    bool have_init = false;
+    {
+        double rho = ETA_START / c.ceta;
+        bool ok = true;
+        for (int it = 0; it < 100; it++) {
+            Eval e = pure_eval(c, rho);
+            if (!(e.dp > 0.0) || !(e.p == e.p)) { ok = false; break; }
+            double step = e.p / e.dp;
+            double rho_new = rho - step;
+            if (!(rho_new > 0.0)) { ok = false; break; }
+            bool conv = fabs(step) <= 1e-8 * rho;
+            rho = rho_new;
+            if (conv) break;
+        }
+        if (ok) {
+            double mu;
+            Eval e = pure_eval_mu(c, rho, mu);
+            if (e.dp > 0.0) {
+                rl = rho;
+                rv = rl * exp(mu);
+                for (int k = 0; k < 60; k++) {
+                    Eval v = pure_eval(c, rv);
+                    if (v.dp > 0.0 && v.p > 0.0 && rv < 0.5 * rl) { have_init = true; break; }
+                    rv *= 0.5;
+                }
+            }
+        }
+    }
+    // 2. spinodal initialisation
+    if (!have_init) {
+        double rho = ETA_START / c.ceta, rho_stable = rho;
+        bool found = false;
+        for (int k = 0; k < 400; k++) {
+            Eval e = pure_eval(c, rho);
+            if (!(e.dp > 0.0)) { found = true; break; }
+            rho_stable = rho;
+            rho *= 0.97;
+        }
+        if (!found) return ST_FAILED;  // super-critical
+        double rho_sl = spinodal_bisect(c, rho, rho_stable, false);
+        double rho_unstable = rho;
+        found = false;
+        for (int k = 0; k < 2000; k++) {
+            rho *= 0.97;
+            Eval e = pure_eval(c, rho);
+            if (e.dp > 0.0) { found = true; break; }
+            rho_unstable = rho;
+        }
+        if (!found) return ST_FAILED;
+        double rho_sv = spinodal_bisect(c, rho, rho_unstable, true);
+        double p_sl = pure_eval(c, rho_sl).p, p_sv = pure_eval(c, rho_sv).p;
+        if (!(p_sv > 0.0)) return ST_FAILED;
+        double p0 = 0.5 * ((p_sl > 0.0 ? p_sl : 0.0) + p_sv);
+        double hi = 0.6 / c.ceta;
+        rl = branch_solve(c, p0, rho_sl, hi, 0.5 * (rho_sl + hi));
+        rv = branch_solve(c, p0, 0.0, rho_sv, 0.5 * rho_sv);
+    }
+    // 3. coupled Newton with backtracking onto the stable branches
+    double err_prev = 1.0;
+    for (int it = 0; it < 100; it++) {
+        Eval l = pure_eval(c, rl);
+        Eval v = pure_eval(c, rv);
+        double p_star = -(v.a / rv - l.a / rl + log(rv / rl)) / (1.0 / rv - 1.0 / rl);
+        double dl = -(l.p - p_star) / l.dp;
+        double dv = -(v.p - p_star) / v.dp;
+        double rl_new = rl + dl, rv_new = rv + dv;
+        for (int k = 0; k < 40; k++) {
+            if (rl_new > 0.0 && pure_eval(c, rl_new).dp > 0.0) break;
+            dl *= 0.5;
+            rl_new = rl + dl;
+        }
+        for (int k = 0; k < 40; k++) {
+            if (rv_new > 0.0 && pure_eval(c, rv_new).dp > 0.0) break;
+            dv *= 0.5;
+            rv_new = rv + dv;
+        }
+        double err = fmax(fabs(dl) / rl, fabs(dv) / rv);
+        out.rho_v = rv;
+        out.rho_l = rl;
+        out.rho_l_new = rl_new;
+        out.p_star = p_star;
+        out.iters = it + 1;
+        rl = rl_new;
+        rv = rv_new;
+        if (!(rl == rl) || !(rv == rv)) return ST_FAILED;
+        bool stagnated = it >= 3 && err < 1e-7 && err >= 0.25 * err_prev;
+        err_prev = err;
+        if (err <= TOL_STEP || stagnated) {
+            if (!(rv < rl * (1.0 - 1e-6))) return ST_FAILED;  // trivial solution
+            return ST_OK;
+        }
+    }
+    return ST_FAILED;
+}
+
+}  // namespace pcs

@@ -1,0 +1,96 @@
+"""Multi-GPU driver: one process per GPU, rows sharded contiguously, outputs re-assembled.
+
+The reference's only parallelism is rayon over independent rows inside one process
+(src/pcsaft.rs:86-92).  Rows never interact, so on a node of MI355X the batch is cut into
+contiguous shards [rank*n/W, (rank+1)*n/W), each rank solves its shard on its own GPU with no
+data-path communication, and a single all-gather (RCCL over xGMI; `nccl` backend == RCCL on
+ROCm) re-assembles `(value fp64, status u8)` on every rank.  Compaction of failed rows happens
+after the gather so message sizes are static.
+
+`compute` is injectable so the sharding/gather logic can be exercised on CPU with the `gloo`
+backend (tests/test_dist_cpu.py); the product default is the HIP path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env():
+    """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).
+    Returns (rank, world, device).  Single-process when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if use_cuda:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, device
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous row range of `rank`: [lo, hi).  Sizes differ by at most one row."""
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return lo, hi
+
+
+def gather_rows(local, n_total, group=None):
+    """All-gather 1-D (or [rows, k]) shards that were cut with shard_bounds() back into the
+    full-length tensor, on every rank.  Shards are padded to the largest shard so the
+    collective has a static message size."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
+    mx = max(sizes)
+    tail = tuple(local.shape[1:])
+    send = local
+    if local.shape[0] != mx:
+        send = torch.zeros((mx,) + tail, dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    send = send.contiguous()
+    recv = torch.empty((world * mx,) + tail, dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:  # gloo: list form
+        parts = list(recv.view((world, mx) + tail).unbind(0))
+        dist.all_gather(parts, send, group=group)
+        recv = torch.stack(parts, 0).view((world * mx,) + tail)
+    if all(s == mx for s in sizes):
+        return recv
+    recv = recv.view((world, mx) + tail)
+    return torch.cat([recv[r, : sizes[r]] for r in range(world)], dim=0)
+
+
+def _hip_vapor_pressure(params, temperature):
+    from . import native
+
+    r = native.pure_vle(params, temperature, want_p=True)
+    return r["p_sat"], r["status"]
+
+
+def sharded_vapor_pressure(params, temperature, compute=None, group=None):
+    """Vapour pressures of the FULL batch (same `params` [n,8] / `temperature` [n] on every
+    rank): each rank solves its contiguous shard, then one all-gather.  Returns dense
+    (p_sat [n], status [n] bool) on every rank."""
+    compute = compute or _hip_vapor_pressure
+    n = temperature.shape[0]
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_bounds(n, rank, world)
+    p_loc, st_loc = compute(params[lo:hi], temperature[lo:hi])
+    p = gather_rows(p_loc, n, group)
+    st = gather_rows(st_loc.to(torch.uint8), n, group).bool()
+    return p, st

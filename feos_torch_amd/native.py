@@ -1,0 +1,191 @@
+"""Device-level wrappers over the C ABI (``include/pcsaft_hip.h``) and the host-side mirror of
+the reference's PyO3 class ``PcSaft`` (src/pcsaft.rs:13-80).
+
+Two layers:
+  * ``pure_vle`` / ``pure_liquid_density`` / ... : torch CUDA(=HIP) tensors in, dense torch
+    tensors out (status mask instead of dropped rows).  Used by the model classes.
+  * ``PcSaft``: numpy in / numpy out with exactly the reference extension's signatures and
+    output layout (failed rows dropped, ``status`` True = failed), so code written against
+    ``feos_torch.feos_torch.PcSaft`` runs unchanged.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_F64 = torch.float64
+
+
+def _dev(device=None):
+    if not torch.cuda.is_available():
+        raise _lib.PcsError(
+            "feos_torch_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback."
+        )
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def _prep(x, device, shape_tail=None):
+    """float64, contiguous, on `device`, detached."""
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.asarray(x, dtype=np.float64))
+    x = x.detach()
+    if x.dtype != _F64:
+        raise TypeError(f"expected float64, got {x.dtype}")  # reference: PyReadonlyArray<f64> type error
+    x = x.to(device).contiguous()
+    if shape_tail is not None and tuple(x.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"expected trailing shape {shape_tail}, got {tuple(x.shape)}")
+    return x
+
+
+def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=False):
+    """Pure VLE on the GPU.  -> dict(p_sat [Pa], rho_eq [kmol/m3], rho_vl [n,2] A^-3, status bool, iters)"""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    params = _prep(params, device, (8,))
+    temperature = _prep(temperature, device)
+    n = temperature.shape[0]
+    if params.shape[0] != n:
+        raise ValueError("parameters and temperature differ in length")
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        p_sat = torch.empty(n, dtype=_F64, device=device) if want_p else None
+        rho_eq = torch.empty(n, dtype=_F64, device=device) if want_rho_eq else None
+        rho_vl = torch.empty((n, 2), dtype=_F64, device=device)
+        status = torch.empty(n, dtype=torch.uint8, device=device)
+        iters = torch.empty(n, dtype=torch.int32, device=device) if want_iters else None
+        ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
+        rc = L.pcs_pure_vle(_lib.ptr(params), _lib.ptr(temperature), n, _lib.ptr(p_sat), _lib.ptr(rho_eq),
+                            _lib.ptr(rho_vl), _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws),
+                            _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_pure_vle")
+    return {"p_sat": p_sat, "rho_eq": rho_eq, "rho_vl": rho_vl, "status": status.bool(), "iters": iters}
+
+
+def pure_liquid_density(params, temperature, pressure):
+    """-> dict(rho [kmol/m3], rho_root [A^-3], status bool)"""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    params = _prep(params, device, (8,))
+    temperature = _prep(temperature, device)
+    pressure = _prep(pressure, device)
+    n = temperature.shape[0]
+    if params.shape[0] != n or pressure.shape[0] != n:
+        raise ValueError("parameters, temperature and pressure differ in length")
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        rho = torch.empty(n, dtype=_F64, device=device)
+        root = torch.empty(n, dtype=_F64, device=device)
+        status = torch.empty(n, dtype=torch.uint8, device=device)
+        rc = L.pcs_pure_liquid_density(_lib.ptr(params), _lib.ptr(temperature), _lib.ptr(pressure), n,
+                                       _lib.ptr(rho), _lib.ptr(root), _lib.ptr(status),
+                                       _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_pure_liquid_density")
+    return {"rho": rho, "rho_root": root, "status": status.bool()}
+
+
+def pure_derivatives(params, temperature, density):
+    """(a, p, dp) reduced — PcSaftPure.derivatives (feos_torch/pcsaft_pure.py:180-182)."""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    params = _prep(params, device, (8,))
+    temperature = _prep(temperature, device)
+    density = _prep(density, device)
+    n = temperature.shape[0]
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        a = torch.empty(n, dtype=_F64, device=device)
+        p = torch.empty(n, dtype=_F64, device=device)
+        dp = torch.empty(n, dtype=_F64, device=device)
+        rc = L.pcs_pure_derivatives(_lib.ptr(params), _lib.ptr(temperature), _lib.ptr(density), n, _lib.ptr(a),
+                                    _lib.ptr(p), _lib.ptr(dp), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_pure_derivatives")
+    return a, p, dp
+
+
+_WHICH = {"vapor_pressure": 0, "liquid_density": 1, "equilibrium_liquid_density": 2}
+
+
+def pure_jacobian(which, params, temperature, pressure, rho_vl):
+    """[n,10] Jacobian w.r.t. (8 parameters, T, p) at fixed densities."""
+    device = rho_vl.device
+    params = _prep(params, device, (8,))
+    temperature = _prep(temperature, device)
+    pressure = None if pressure is None else _prep(pressure, device)
+    rho_vl = _prep(rho_vl, device, (2,))
+    n = temperature.shape[0]
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        jac = torch.empty((n, 10), dtype=_F64, device=device)
+        rc = L.pcs_pure_jacobian(_WHICH[which], _lib.ptr(params), _lib.ptr(temperature), _lib.ptr(pressure),
+                                 _lib.ptr(rho_vl), n, _lib.ptr(jac), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_pure_jacobian")
+    return jac
+
+
+class PcSaft:
+    """Mirror of the reference's Rust pyclass ``PcSaft`` (src/pcsaft.rs:13-80): static methods,
+    float64 numpy arrays in, ``(rho, status)`` numpy arrays out, failed rows dropped from ``rho``."""
+
+    @staticmethod
+    def vapor_pressure(parameters, temperature):
+        """src/pcsaft.rs:18-26 — rho[n_ok, 4]: col 0 = rho_V, col 1 = rho_L, cols 2-3 zero (:94-101)."""
+        parameters = _as_f64(parameters, 2)
+        temperature = _as_f64(temperature, 1)
+        r = pure_vle(torch.from_numpy(parameters), torch.from_numpy(temperature), want_p=False)
+        status = r["status"].cpu().numpy()
+        rho = np.zeros((int((~status).sum()), 4))
+        rho[:, 0:2] = r["rho_vl"].cpu().numpy()[~status]
+        return rho, status
+
+    @staticmethod
+    def liquid_density(parameters, temperature, pressure):
+        """src/pcsaft.rs:28-41 — rho[n_ok]."""
+        parameters = _as_f64(parameters, 2)
+        temperature = _as_f64(temperature, 1)
+        pressure = _as_f64(pressure, 1)
+        r = pure_liquid_density(torch.from_numpy(parameters), torch.from_numpy(temperature),
+                                torch.from_numpy(pressure))
+        status = r["status"].cpu().numpy()
+        return r["rho_root"].cpu().numpy()[~status], status
+
+
+def _as_f64(x, ndim):
+    x = np.asarray(x)
+    if x.dtype != np.float64:
+        raise TypeError(f"argument must be a float64 array, got {x.dtype}")  # PyReadonlyArray<f64>
+    if x.ndim != ndim:
+        raise TypeError(f"argument must be {ndim}-dimensional, got {x.ndim}")
+    return np.ascontiguousarray(x)
+
+
+class PureVlePlan:
+    """Pre-allocated launch plan for repeated pure-VLE solves on a fixed number of rows: all
+    outputs and the retry workspace are allocated once; ``run`` only enqueues kernels on the
+    current HIP stream (no allocation, no host synchronisation), so steps can be timed with
+    HIP events or captured into a hipGraph."""
+
+    def __init__(self, n, device, want_rho_eq=False, want_rho_vl=False):
+        self.n = int(n)
+        self.device = torch.device(device)
+        self._L = _lib.lib()
+        with torch.cuda.device(self.device):
+            self.p_sat = torch.empty(self.n, dtype=_F64, device=self.device)
+            self.rho_eq = torch.empty(self.n, dtype=_F64, device=self.device) if want_rho_eq else None
+            self.rho_vl = torch.empty((self.n, 2), dtype=_F64, device=self.device) if want_rho_vl else None
+            self.status = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+            self.ws = torch.empty(max(1, self._L.pcs_workspace_bytes(self.n) // 4), dtype=torch.int32,
+                                  device=self.device)
+
+    def _args(self, params, temperature):
+        return (_lib.ptr(params), _lib.ptr(temperature), self.n, _lib.ptr(self.p_sat), _lib.ptr(self.rho_eq),
+                _lib.ptr(self.rho_vl), _lib.ptr(self.status), None, _lib.ptr(self.ws),
+                _lib.current_stream_ptr(self.device))
+
+    def run(self, params, temperature):
+        _lib.check(self._L.pcs_pure_vle(*self._args(params, temperature)), "pcs_pure_vle")
+
+    def run_fast(self, params, temperature):
+        _lib.check(self._L.pcs_pure_vle_fast(*self._args(params, temperature)), "pcs_pure_vle_fast")
+
+    def run_retry(self, params, temperature):
+        _lib.check(self._L.pcs_pure_vle_retry(*self._args(params, temperature)), "pcs_pure_vle_retry")
+
+    def retry_count(self):
+        return int(self.ws[0].item())

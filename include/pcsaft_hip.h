@@ -1,0 +1,105 @@
+/*
+ * pcsaft_hip.h — C ABI of libpcsaft_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the native half of feos-torch.  Each entry point replaces one method
+ * of the reference's PyO3 classes (module `feos_torch.feos_torch`, src/lib.rs:10-16) together
+ * with the per-row feos solve behind it, and additionally returns the property the reference's
+ * Python tail computes from the converged densities (the kernels produce it in the same pass).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch tensor .data_ptr()), fp64 unless
+ *     noted, C-contiguous; the caller owns all memory; nothing is allocated or freed here;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     the call returns without synchronising;
+ *   - outputs are DENSE (length n): status[i] = 1 marks a row the solver could not converge
+ *     (the reference drops such rows, src/pcsaft.rs:93-95; compaction is left to the caller);
+ *   - optional outputs may be NULL;
+ *   - return value 0 = enqueued, non-zero = API error, message via pcs_last_error();
+ *   - parameter row layout (README.md:12): m, sigma[A], epsilon_k[K], mu[D], kappa_ab,
+ *     epsilon_k_ab[K], na, nb.
+ */
+#ifndef PCSAFT_HIP_H
+#define PCSAFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / ABI version (major*100 + minor). */
+int pcs_abi_version(void);
+
+/* Last error message of the calling thread ("" if none). */
+const char* pcs_last_error(void);
+
+/* Bytes of device scratch a call on n rows needs (retry list for the robust pass). */
+int64_t pcs_workspace_bytes(int64_t n);
+
+/*
+ * Pure-component VLE at fixed temperature.
+ * Replaces PcSaft.vapor_pressure(parameters[N,8], temperature[N]) -> (rho[n_ok,4], status[N])
+ * (src/pcsaft.rs:18-26, :82-103) and the Python tails of PcSaftPure.vapor_pressure
+ * (feos_torch/pcsaft_pure.py:201-215) and .equilibrium_liquid_density (:217-233).
+ *   params   [n,8]   in
+ *   temp     [n]     in   K
+ *   p_sat    [n]     out  Pa            (optional)  pcsaft_pure.py:214-215
+ *   rho_eq   [n]     out  kmol/m3       (optional)  pcsaft_pure.py:232-233
+ *   rho_vl   [n,2]   out  A^-3: (rho_V, rho_L) at which the formulas were evaluated (optional;
+ *                         the reference's rho[:,0:2] of src/pcsaft.rs:99-100)
+ *   status   [n]     out  uint8, 1 = failed
+ *   iters    [n]     out  int32, Newton iterations used (optional, diagnostics)
+ *   workspace        device scratch of pcs_workspace_bytes(n)
+ */
+int pcs_pure_vle(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                 double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);
+
+/*
+ * The two stages of pcs_pure_vle as separate launches, same arguments (for per-kernel timing and
+ * for callers that want to overlap the rare-row robust pass with other work):
+ *   pcs_pure_vle_fast   zeroes the retry counter, runs the fast kernel on all n rows and appends
+ *                       rows that need the robust initialisation to the workspace list;
+ *   pcs_pure_vle_retry  runs the robust kernel over that list (count read on the device).
+ * pcs_pure_vle == pcs_pure_vle_fast followed by pcs_pure_vle_retry on the same stream.
+ */
+int pcs_pure_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                      double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);
+int pcs_pure_vle_retry(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                       double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);
+
+/*
+ * Liquid density at given (T, p).
+ * Replaces PcSaft.liquid_density(parameters[N,8], temperature[N], pressure[N]) ->
+ * (rho[n_ok], status[N]) (src/pcsaft.rs:28-41, :105-129) and the tail of
+ * PcSaftPure.liquid_density (feos_torch/pcsaft_pure.py:184-199).
+ *   pressure [n]  in   Pa
+ *   rho_out  [n]  out  kmol/m3  (optional)  pcsaft_pure.py:198-199
+ *   rho_root [n]  out  A^-3 density at which the final Newton step was taken (optional)
+ */
+int pcs_pure_liquid_density(const double* params, const double* temp, const double* pressure, int64_t n,
+                            double* rho_out, double* rho_root, uint8_t* status, void* stream);
+
+/*
+ * (a, p, dp/drho) at given (T, rho) — PcSaftPure.derivatives (feos_torch/pcsaft_pure.py:180-182).
+ * All reduced (A^-3).  Any output may be NULL.
+ */
+int pcs_pure_derivatives(const double* params, const double* temp, const double* rho, int64_t n, double* a,
+                         double* p, double* dp, void* stream);
+
+/*
+ * Jacobian of a pure-component property w.r.t. its inputs with the phase densities held
+ * fixed — what torch reverse mode through the reference's Python tail yields
+ * (feos_torch/pcsaft_pure.py:196-199 / :212-215 / :228-233).
+ *   which    0 = vapor_pressure, 1 = liquid_density, 2 = equilibrium_liquid_density
+ *   pressure [n]    in  Pa (which = 1 only, else NULL)
+ *   rho_vl   [n,2]  in  A^-3 (rho_V, rho_L) from pcs_pure_vle; for which = 1 column 1 holds
+ *                       rho_root from pcs_pure_liquid_density, column 0 is ignored
+ *   jac      [n,10] out d value / d (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb, T, p)
+ */
+int pcs_pure_jacobian(int which, const double* params, const double* temp, const double* pressure,
+                      const double* rho_vl, int64_t n, double* jac, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCSAFT_HIP_H */

@@ -1,0 +1,160 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of the CPU restatement in this directory (``liboracle.so``).  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product package ``feos_torch_amd`` never does.
+
+Every function takes/returns numpy float64 arrays.  ``prec=1`` runs the solver in x87
+``long double`` with a 1e-17 step tolerance (results rounded to double) and is the parity
+reference; ``prec=0`` is the plain-double port that the benchmark times as ``cpu_baseline``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+
+def build(force=False):
+    """Compile the oracle with g++ (``make -C oracle``)."""
+    if force or not os.path.exists(_LIB_PATH) or _stale():
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def _stale():
+    t = os.path.getmtime(_LIB_PATH)
+    for f in os.listdir(_HERE):
+        if f.endswith((".hpp", ".cpp")) and os.path.getmtime(os.path.join(_HERE, f)) > t:
+            return True
+    return False
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.orc_num_threads.restype = _int
+        L.orc_dual3_selftest.restype = _int
+        L.orc_pure_derivatives.argtypes = [_f64p, _f64p, _f64p, _i64, _f64p, _f64p, _f64p]
+        L.orc_pure_helmholtz.argtypes = [_f64p, _f64p, _f64p, _i64, _f64p]
+        L.orc_pure_vle.argtypes = [_f64p, _f64p, _i64, _int, _f64p, _f64p, _u8p, _i32p, _i32p]
+        L.orc_pure_vapor_pressure.argtypes = [_f64p, _f64p, _i64, _int, _f64p, _u8p]
+        L.orc_pure_vapor_pressure_at.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p]
+        L.orc_pure_liquid_density.argtypes = [_f64p, _f64p, _f64p, _i64, _int, _f64p, _u8p]
+        L.orc_pure_liquid_density_root.argtypes = [_f64p, _f64p, _f64p, _i64, _int, _f64p, _u8p]
+        L.orc_pure_equilibrium_liquid_density.argtypes = [_f64p, _f64p, _i64, _int, _f64p, _u8p]
+        L.orc_pure_property_grad.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _f64p, _f64p]
+        _lib = L
+    return _lib
+
+
+def dual3_selftest():
+    return lib().orc_dual3_selftest()
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def _c(x, shape=None):
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    if shape is not None:
+        assert x.shape == shape, (x.shape, shape)
+    return x
+
+
+def pure_derivatives(params, T, rho):
+    params, T, rho = _c(params), _c(T), _c(rho)
+    n = T.shape[0]
+    a, p, dp = np.empty(n), np.empty(n), np.empty(n)
+    lib().orc_pure_derivatives(params, T, rho, n, a, p, dp)
+    return a, p, dp
+
+
+def pure_helmholtz(params, T, rho):
+    params, T, rho = _c(params), _c(T), _c(rho)
+    a = np.empty(T.shape[0])
+    lib().orc_pure_helmholtz(params, T, rho, T.shape[0], a)
+    return a
+
+
+def pure_vle(params, T, prec=1):
+    """-> rho_v, rho_l [A^-3], status (True = failed), iters, path"""
+    params, T = _c(params), _c(T)
+    n = T.shape[0]
+    rv, rl = np.empty(n), np.empty(n)
+    st = np.empty(n, dtype=np.uint8)
+    it, path = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+    lib().orc_pure_vle(params, T, n, prec, rv, rl, st, it, path)
+    return rv, rl, st.astype(bool), it, path
+
+
+def pure_vapor_pressure(params, T, prec=1):
+    """-> p [Pa] (dense, 0 where failed), status (True = failed)"""
+    params, T = _c(params), _c(T)
+    n = T.shape[0]
+    p = np.empty(n)
+    st = np.empty(n, dtype=np.uint8)
+    lib().orc_pure_vapor_pressure(params, T, n, prec, p, st)
+    return p, st.astype(bool)
+
+
+def pure_vapor_pressure_at(params, T, rho_v, rho_l):
+    params, T, rho_v, rho_l = _c(params), _c(T), _c(rho_v), _c(rho_l)
+    p = np.empty(T.shape[0])
+    lib().orc_pure_vapor_pressure_at(params, T, rho_v, rho_l, T.shape[0], p)
+    return p
+
+
+def pure_liquid_density(params, T, p_pa, prec=1):
+    """-> rho [kmol/m3] (dense), status"""
+    params, T, p_pa = _c(params), _c(T), _c(p_pa)
+    n = T.shape[0]
+    rho = np.empty(n)
+    st = np.empty(n, dtype=np.uint8)
+    lib().orc_pure_liquid_density(params, T, p_pa, n, prec, rho, st)
+    return rho, st.astype(bool)
+
+
+def pure_liquid_density_root(params, T, p_pa, prec=1):
+    """-> converged liquid density [A^-3] (dense), status"""
+    params, T, p_pa = _c(params), _c(T), _c(p_pa)
+    n = T.shape[0]
+    rho = np.empty(n)
+    st = np.empty(n, dtype=np.uint8)
+    lib().orc_pure_liquid_density_root(params, T, p_pa, n, prec, rho, st)
+    return rho, st.astype(bool)
+
+
+def pure_equilibrium_liquid_density(params, T, prec=1):
+    params, T = _c(params), _c(T)
+    n = T.shape[0]
+    rho = np.empty(n)
+    st = np.empty(n, dtype=np.uint8)
+    lib().orc_pure_equilibrium_liquid_density(params, T, n, prec, rho, st)
+    return rho, st.astype(bool)
+
+
+def pure_property_grad(which, params, T, p_pa, rho_v, rho_l):
+    """value[n], grad[n,10] (d/d 8 params, T, p_spec) with densities held fixed."""
+    params, T = _c(params), _c(T)
+    n = T.shape[0]
+    p_pa = _c(p_pa if p_pa is not None else np.zeros(n))
+    rho_v = _c(rho_v if rho_v is not None else np.zeros(n))
+    rho_l = _c(rho_l)
+    val, grad = np.empty(n), np.empty((n, 10))
+    lib().orc_pure_property_grad({"vapor_pressure": 0, "liquid_density": 1, "equilibrium_liquid_density": 2}[which],
+                                 params, T, p_pa, rho_v, rho_l, n, val, grad)
+    return val, grad

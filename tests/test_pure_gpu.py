@@ -1,0 +1,256 @@
+"""GPU parity tests for the pure-component hot path (configs 1-3 of BASELINE.json).
+
+Every call goes through the C ABI of libpcsaft_hip.so (via feos_torch_amd).  Checks, in the
+shape of the reference's tests/test_pcsaft_pure.py:
+  * (a, p, dp) against the golden vectors of the unmodified reference Python (abs 1e-10 is
+    the reference's own tolerance, tests/test_pcsaft_pure.py:59-61);
+  * vapor_pressure / liquid_density / equilibrium_liquid_density against the golden values
+    (reference tolerance rel 1e-10, :69/:80/:88; north_star rtol 1e-9) and against the
+    long-double CPU oracle on seeded random batches;
+  * autograd gradients against the reference's torch gradients (golden) and finite differences
+    (rel 1e-4, :113/:137/:161);
+  * size-independent properties at the benchmark's full batch (1e7): phase-equilibrium
+    residuals p(rho_V) = p(rho_L) = p_sat and equal chemical potentials;
+  * edge cases: empty batch, ragged batch (n % 256 != 0), failed rows, model mutation.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9  # BASELINE.json north_star: "matching feos CPU to rtol 1e-9"
+PROPS = ("vapor_pressure", "liquid_density", "equilibrium_liquid_density")
+P_UNIT = 1.380649e-23 / (1e-10 * 1e-10 * 1e-10)
+f64 = torch.float64
+
+
+@pytest.fixture(scope="module")
+def amd():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import feos_torch_amd
+
+    return feos_torch_amd
+
+
+def _t(x, **kw):
+    return torch.tensor(np.asarray(x), dtype=f64, **kw)
+
+
+def _call(eos, prop, T, p):
+    if prop == "liquid_density":
+        return eos.liquid_density(T, p)
+    return getattr(eos, prop)(T)
+
+
+# ------------------------------------------------------------------------------------------
+# golden vectors from the reference Python
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["test_inputs", "readme", "random"])
+def test_derivatives_vs_reference_python(amd, golden_pure, case):
+    g = golden_pure[case]
+    eos = amd.PcSaftPure(_t(g["params"]))
+    a, p, dp = eos.derivatives(_t(g["T"]), _t(g["rho"]))
+    for got, key in ((a, "a"), (p, "p"), (dp, "dp")):
+        want = np.array(g[key])
+        err = np.abs(got.numpy() - want) / np.maximum(1.0, np.abs(want))
+        assert err.max() < 1e-10, (key, err.max())  # tests/test_pcsaft_pure.py:59-61
+
+
+def test_readme_example(amd, golden_pure):
+    """README.md:10-29 verbatim (CPU tensors in, CPU tensors out)."""
+    params = torch.tensor([1.5, 3.5, 250.0, 0, 0.03, 1500.0, 1, 1], dtype=f64, requires_grad=True)
+    pcsaft = amd.PcSaftPure(params.repeat(5, 1))
+    temperature = torch.tensor([250.0, 300.0, 350.0, 400.0, 450.0], dtype=f64)
+    _, vp = pcsaft.vapor_pressure(temperature)
+    vp[0].backward()
+    g = golden_pure["readme"]
+    assert np.all(np.abs(vp.detach().numpy() - np.array(g["readme_vapor_pressure_printed"])) < 0.5001e-4)
+    want = np.array(g["readme_grad_printed"])
+    got = params.grad.numpy()
+    assert got[3] == 0.0
+    nz = want != 0
+    assert np.all(np.abs(got[nz] / want[nz] - 1) < 1e-4)
+
+
+@pytest.mark.parametrize("case", ["test_inputs", "readme", "random"])
+@pytest.mark.parametrize("prop", PROPS)
+def test_properties_and_gradients_vs_reference_python(amd, golden_pure, case, prop):
+    g = golden_pure[case]
+    ref = g["properties"][prop]
+    x = _t(g["params"], requires_grad=True)
+    T = _t(g["T"], requires_grad=True)
+    p = _t(g.get("p_spec", [1e5] * len(g["T"])), requires_grad=True)
+    eos = amd.PcSaftPure(x)
+    nans, val = _call(eos, prop, T, p)
+    assert nans.tolist() == ref["nans"]
+    want = np.array(ref["value"])
+    assert np.max(np.abs(val.detach().numpy() / want - 1)) < 1e-10  # tests/test_pcsaft_pure.py:69,80,88
+    val.sum().backward()
+    got = np.concatenate([x.grad.numpy(), T.grad.numpy()[:, None]], axis=1)
+    wantg = np.concatenate([np.array(ref["grad_params"]), np.array(ref["grad_T"])[:, None]], axis=1)
+    if prop == "liquid_density":
+        got = np.concatenate([got, p.grad.numpy()[:, None]], axis=1)
+        wantg = np.concatenate([wantg, np.array(ref["grad_p"])[:, None]], axis=1)
+    ok = ~np.array(ref["nans"])
+    scale = np.abs(wantg[ok]).max(axis=1, keepdims=True)
+    assert np.max(np.abs(got[ok] - wantg[ok]) / scale) < 1e-7
+    assert np.all(got[~ok] == 0.0)
+
+
+# ------------------------------------------------------------------------------------------
+# gradients vs finite differences (tests/test_pcsaft_pure.py:91-161)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize(
+    "prop,params,h",
+    [
+        ("liquid_density", [1.5, 3.2, 150, 2.5, 0.03, 2500, 1, 1], 5e-9),
+        ("vapor_pressure", [1.5, 3.2, 150, 2.5, 0.03, 2500, 1, 2], 5e-9),
+        ("equilibrium_liquid_density", [1.5, 3.2, 150, 2.5, 0.03, 2500, 2, 1], 5e-7),
+    ],
+)
+def test_gradients_vs_finite_differences(amd, prop, params, h):
+    T = torch.tensor([300.0], dtype=f64)
+    p = torch.tensor([1e5], dtype=f64)
+    x = torch.tensor([params], dtype=f64, requires_grad=True)
+    _call(amd.PcSaftPure(x), prop, T, p)[1].backward()
+    v0 = _call(amd.PcSaftPure(x), prop, T, p)[1]
+    for i in range(6):
+        hi = params[i] * h
+        xh = [xj + hi if j == i else xj for j, xj in enumerate(params)]
+        vh = _call(amd.PcSaftPure(torch.tensor([xh], dtype=f64)), prop, T, p)[1]
+        fd = ((vh - v0) / hi).item()
+        assert abs((fd - x.grad[0, i].item()) / x.grad[0, i].item()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------
+# random batches vs the long-double oracle
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 63, 257, 100_003])
+def test_random_batch_vs_oracle(amd, oracle, n):
+    from feos_torch_amd.synthetic import pure_batch, pure_pressures
+
+    P, T = pure_batch(n, seed=100 + n)
+    psp = pure_pressures(n, seed=200 + n)
+    dev = "cuda"
+    for prop in PROPS:
+        eos = amd.PcSaftPure(_t(P).to(dev))
+        nans, val = _call(eos, prop, _t(T).to(dev), _t(psp).to(dev))
+        assert val.is_cuda and nans.dtype == torch.bool and nans.shape == (n,)
+        if prop == "vapor_pressure":
+            want, st = oracle.pure_vapor_pressure(P, T, prec=1)
+        elif prop == "liquid_density":
+            want, st = oracle.pure_liquid_density(P, T, psp, prec=1)
+        else:
+            want, st = oracle.pure_equilibrium_liquid_density(P, T, prec=1)
+        nans = nans.cpu().numpy()
+        assert (nans != st).sum() <= max(1, n // 20000), "failure masks differ"
+        both = ~nans & ~st
+        got = np.zeros(n)
+        got[~nans] = val.cpu().numpy()
+        assert np.max(np.abs(got[both] / want[both] - 1)) < RTOL
+        assert eos.parameters.shape[0] == int((~nans).sum())  # model was reduced (pcsaft_pure.py:235-243)
+
+
+def test_jacobian_vs_oracle(amd, oracle):
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch, pure_pressures
+
+    n = 4099
+    P, T = pure_batch(n, seed=5)
+    psp = pure_pressures(n, seed=6)
+    Pd, Td, pd = _t(P).cuda(), _t(T).cuda(), _t(psp).cuda()
+    r = native.pure_vle(Pd, Td)
+    ok = ~r["status"].cpu().numpy()
+    rho_vl = r["rho_vl"].cpu().numpy()
+    for prop in ("vapor_pressure", "equilibrium_liquid_density"):
+        J = native.pure_jacobian(prop, Pd, Td, None, r["rho_vl"]).cpu().numpy()
+        _, want = oracle.pure_property_grad(prop, P, T, None, rho_vl[:, 0], rho_vl[:, 1])
+        scale = np.abs(want[ok]).max(axis=1, keepdims=True)
+        assert np.max(np.abs(J[ok] - want[ok]) / scale) < 1e-7, prop
+    r2 = native.pure_liquid_density(Pd, Td, pd)
+    ok = ~r2["status"].cpu().numpy()
+    rho_vl = torch.stack([torch.zeros_like(r2["rho_root"]), r2["rho_root"]], dim=1)
+    J = native.pure_jacobian("liquid_density", Pd, Td, pd, rho_vl).cpu().numpy()
+    _, want = oracle.pure_property_grad("liquid_density", P, T, psp, None, r2["rho_root"].cpu().numpy())
+    scale = np.abs(want[ok]).max(axis=1, keepdims=True)
+    assert np.max(np.abs(J[ok] - want[ok]) / scale) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------
+# full benchmark size: size-independent properties (no oracle at 1e7 rows)
+# ------------------------------------------------------------------------------------------
+def test_full_batch_equilibrium_conditions(amd, oracle):
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch
+
+    n = 10_000_000
+    P, T = pure_batch(n)
+    Pd, Td = _t(P).cuda(), _t(T).cuda()
+    r = native.pure_vle(Pd, Td, want_p=True, want_rho_eq=True)
+    ok = ~r["status"]
+    assert ok.float().mean().item() > 0.9999
+    rv, rl = r["rho_vl"][:, 0], r["rho_vl"][:, 1]
+    a_v, p_v, _ = native.pure_derivatives(Pd, Td, rv)
+    a_l, p_l, dp_l = native.pure_derivatives(Pd, Td, rl)
+    p_red = r["p_sat"] / (Td * P_UNIT)
+    # mechanical equilibrium.  The liquid residual is resolved only to |a|*eps/p (p_L is a
+    # difference of O(0.1) terms), so it is checked as the density error it implies: |dp|/(dp/drho rho)
+    assert torch.max(torch.abs(p_v[ok] / p_red[ok] - 1)).item() < 1e-8
+    assert torch.max(torch.abs((p_l[ok] - p_red[ok]) / (dp_l[ok] * rl[ok]))).item() < 1e-9
+    # chemical equilibrium: g = a/rho + p/rho + ln rho  equal in both phases
+    g_v = (a_v + p_v) / rv + torch.log(rv)
+    g_l = (a_l + p_l) / rl + torch.log(rl)
+    assert torch.max(torch.abs(g_v[ok] - g_l[ok])).item() < 1e-8
+    assert torch.all(rv[ok] < rl[ok])
+    # a slice against the oracle
+    idx = slice(5_000_000, 5_020_000)
+    want, st = oracle.pure_vapor_pressure(P[idx], T[idx], prec=1)
+    got = r["p_sat"][idx].cpu().numpy()
+    both = ~st & ok[idx].cpu().numpy()
+    assert np.max(np.abs(got[both] / want[both] - 1)) < RTOL
+
+
+# ------------------------------------------------------------------------------------------
+# edge cases
+# ------------------------------------------------------------------------------------------
+def test_empty_batch(amd):
+    eos = amd.PcSaftPure(torch.zeros((0, 8), dtype=f64))
+    nans, vp = eos.vapor_pressure(torch.zeros(0, dtype=f64))
+    assert nans.shape == (0,) and vp.shape == (0,)
+
+
+def test_failed_rows_are_dropped_and_model_is_reduced(amd):
+    # row 1 is super-critical: no VLE.  Reference behaviour: nans[1] = True, outputs have n_ok rows,
+    # the model object is filtered (src/pcsaft.rs:93-95, feos_torch/pcsaft_pure.py:207-208)
+    par = _t([[1.5, 3.2, 150.0, 0, 0, 0, 0, 0]] * 3, requires_grad=True)
+    eos = amd.PcSaftPure(par)
+    nans, vp = eos.vapor_pressure(_t([100.0, 400.0, 110.0]))
+    assert nans.tolist() == [False, True, False]
+    assert vp.shape == (2,)
+    assert eos.m.shape == (2,) and eos.parameters.shape == (2, 8)
+    vp.sum().backward()
+    assert torch.all(par.grad[1] == 0) and torch.all(par.grad[0, :3] != 0)
+
+
+def test_dtype_is_checked(amd):
+    eos = amd.PcSaftPure(torch.ones((1, 8), dtype=torch.float32))
+    with pytest.raises(TypeError):
+        eos.vapor_pressure(torch.tensor([300.0], dtype=torch.float32))
+
+
+def test_ffi_mirror_layout(amd, oracle):
+    """PcSaft.vapor_pressure / liquid_density keep the Rust extension's numpy contract
+    (src/pcsaft.rs:18-41, :93-101): rho[n_ok,4] with cols 0,1 = (rho_V, rho_L), status[N] bool."""
+    par = np.array([[1.5, 3.2, 150.0, 0, 0, 0, 0, 0]] * 3)
+    T = np.array([100.0, 400.0, 110.0])
+    rho, status = amd.PcSaft.vapor_pressure(par, T)
+    assert rho.shape == (2, 4) and rho.dtype == np.float64 and status.dtype == bool
+    assert status.tolist() == [False, True, False]
+    assert np.all(rho[:, 2:] == 0) and np.all(rho[:, 0] < rho[:, 1])
+    rv, rl, st, _, _ = oracle.pure_vle(par, T, prec=1)
+    assert np.max(np.abs(rho[:, 0] / rv[~st] - 1)) < 1e-8 and np.max(np.abs(rho[:, 1] / rl[~st] - 1)) < 1e-8
+    rho1, st1 = amd.PcSaft.liquid_density(par, T, np.full(3, 1e5))
+    assert rho1.ndim == 1 and st1.shape == (3,)
+    with pytest.raises(TypeError):
+        amd.PcSaft.vapor_pressure(par.astype(np.float32), T)
