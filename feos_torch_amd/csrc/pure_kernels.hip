@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BLOCK) void k_pure_vle(const double* __restrict__ p
     if (!live) return;
     if (st == ST_OK) {
         if (p_sat) p_sat[i] = r.p_star * T * P_UNIT;
-        if (rho_eq) rho_eq[i] = r.rho_l_new * (1.0 / RHO_UNIT);
+        if (rho_eq) rho_eq[i] = r.rho_l * (1.0 / RHO_UNIT);
         if (rho_vl) {
             rho_vl[2 * i] = r.rho_v;
             rho_vl[2 * i + 1] = r.rho_l;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_pure_vle_robust(const double* __restrict
         int st = vle_robust(c, r);
         if (st == ST_OK) {
             if (p_sat) p_sat[i] = r.p_star * T * P_UNIT;
-            if (rho_eq) rho_eq[i] = r.rho_l_new * (1.0 / RHO_UNIT);
+            if (rho_eq) rho_eq[i] = r.rho_l * (1.0 / RHO_UNIT);
             if (rho_vl) {
                 rho_vl[2 * i] = r.rho_v;
                 rho_vl[2 * i + 1] = r.rho_l;
@@ -161,11 +161,12 @@ __global__ __launch_bounds__(BLOCK) void k_pure_liquid_density(const double* __r
     Eval last;
     int st = liquid_newton(c, p_red, TOL_STEP, rho, last);
     if (!live) return;
-    // `rho` already carries the final Newton update; the point it was taken at:
-    double root = rho + (last.p - p_red) / last.dp;
+    // `rho` already carries the final Newton update rho - (p - p_spec)/dp (pcsaft_pure.py:198) taken
+    // at a point whose relative step was <= TOL_STEP, i.e. it is converged to ~1e-11; it is both
+    // the returned property and the density reported as the root.
     bool ok = (st == ST_OK);
     if (rho_out) rho_out[i] = ok ? rho * (1.0 / RHO_UNIT) : 0.0;
-    if (rho_root) rho_root[i] = ok ? root : 0.0;
+    if (rho_root) rho_root[i] = ok ? rho : 0.0;
     status[i] = ok ? 0 : 1;
 }
 

@@ -48,7 +48,7 @@ PCS_DEV Eval pure_eval_mu(const PureCoef<double>& c, double rho, double& mu_res)
 constexpr int LIQ_MAX_IT = 40;
 constexpr int VLE_MAX_IT = 40;
 constexpr double ETA_START = 0.5;
-constexpr double TOL_STEP = 1e-10;  // relative Newton step at which a lane is converged
+constexpr double TOL_STEP = 1e-6;  // relative Newton step at which a lane is converged (see vle_step)
 
 // Newton for p(rho) = p_spec from the dense side.  Returns ST_OK with the converged density
 // (rho) and the LAST Newton update already applied (so rho is also the reference's final
@@ -86,58 +86,74 @@ PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, 
 }
 
 struct VleResult {
-    double rho_v, rho_l;   // densities BEFORE the last Newton update (where p* was evaluated)
-    double rho_l_new;      // liquid density after the last update  (pcsaft_pure.py:232)
-    double p_star;         // equal-area pressure, reduced            (pcsaft_pure.py:214 / :231)
+    double rho_v, rho_l;   // phase densities after the last Newton update (the converged state)
+    double p_star;         // equal-area pressure at that state, reduced   (pcsaft_pure.py:214 / :231)
     int iters;
 };
+
+// One coupled Newton update from evaluations l, v at (rl, rv):
+//   p*  = -(f_V - f_L)/(v_V - v_L),  f = a/rho + ln rho          (== pcsaft_pure.py:214)
+//   rho_k <- rho_k - (p_k - p*)/p'_k   for both phases           (liquid: == pcsaft_pure.py:232)
+// p* is stationary w.r.t. both densities at the solution, so its value at the UPDATED densities
+// is p* + 1/2 [ (p_V-p*)^2/(rho_V^2 p'_V) - (p_L-p*)^2/(rho_L^2 p'_L) ] / (v_V - v_L) + O(step^3):
+// the pressure is taken with this second-order term, which makes it exact to ~1e-17 once the
+// relative steps are below TOL_STEP = 1e-6 and saves the confirming iteration.
+struct VleStep {
+    double p_star, p_corr, dl, dv;
+};
+PCS_DEV VleStep vle_step(const Eval& l, const Eval& v, double rl, double rv) {
+    VleStep s;
+    double inv_v = 1.0 / rv, inv_l = 1.0 / rl;
+    double inv_dv = 1.0 / (inv_v - inv_l);
+    s.p_star = -(v.a * inv_v - l.a * inv_l + log(rv * inv_l)) * inv_dv;
+    double rl_res = l.p - s.p_star, rv_res = v.p - s.p_star;
+    double il = 1.0 / l.dp, iv = 1.0 / v.dp;
+    s.dl = -rl_res * il;
+    s.dv = -rv_res * iv;
+    s.p_corr = s.p_star + 0.5 * ((rv_res * rv_res) * (inv_v * inv_v) * iv - (rl_res * rl_res) * (inv_l * inv_l) * il) * inv_dv;
+    return s;
+}
 
 // Fast path of the pure VLE: zero-pressure liquid + ideal-gas vapour initialisation, then the
 // coupled Newton.  ST_RETRY = this initialisation does not apply (near-critical temperature);
 // the robust kernel takes those rows.
 PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
     double rl;
-    Eval el;
-    int st = liquid_newton(c, 0.0, 1e-3, rl, el);
+    Eval l;
+    int st = liquid_newton(c, 0.0, 1e-3, rl, l);
     bool active = (st == ST_OK);
     double rv = 0.0;
-    if (active) {
+    {
         double mu;
-        Eval e = pure_eval_mu(c, rl, mu);
-        if (!(e.dp > 0.0)) active = false;
+        l = pure_eval_mu(c, rl, mu);  // all lanes (wave-uniform call); also the first liquid evaluation
+        if (!(l.dp > 0.0)) active = false;
         rv = rl * exp(mu);  // ln rho_V = ln rho_L + a'(rho_L): ideal vapour at the liquid's fugacity
-        // non-ideal vapour estimates are left to the robust path
+        // strongly non-ideal vapour estimates are left to the robust path
         if (!(rv < 0.05 * rl)) active = false;
     }
-    bool retry = !active;
     bool done = false;
     out.iters = 0;
     for (int it = 0; it < VLE_MAX_IT; it++) {
         if (active && !done) {
-            Eval l = pure_eval(c, rl);
             Eval v = pure_eval(c, rv);
-            double inv_v = 1.0 / rv, inv_l = 1.0 / rl;
-            double p_star = -(v.a * inv_v - l.a * inv_l + log(rv * inv_l)) / (inv_v - inv_l);
-            double dl = -(l.p - p_star) / l.dp;
-            double dv = -(v.p - p_star) / v.dp;
-            bool ok = (l.dp > 0.0) && (v.dp > 0.0) && (p_star == p_star);
-            double rl_new = rl + dl, rv_new = rv + dv;
+            VleStep s = vle_step(l, v, rl, rv);
+            bool ok = (l.dp > 0.0) && (v.dp > 0.0) && (s.p_star == s.p_star);
+            double rl_new = rl + s.dl, rv_new = rv + s.dv;
             ok = ok && (rl_new > 0.0) && (rv_new > 0.0) && (rv_new < rl_new);
             if (!ok) {
                 active = false;
-                retry = true;
             } else {
-                out.rho_v = rv;
-                out.rho_l = rl;
-                out.rho_l_new = rl_new;
-                out.p_star = p_star;
-                out.iters = it + 1;
-                done = (fabs(dl) <= TOL_STEP * rl) && (fabs(dv) <= TOL_STEP * rv);
+                done = (fabs(s.dl) <= TOL_STEP * rl) && (fabs(s.dv) <= TOL_STEP * rv);
                 rl = rl_new;
                 rv = rv_new;
+                out.rho_v = rv;
+                out.rho_l = rl;
+                out.p_star = s.p_corr;
+                out.iters = it + 1;
             }
         }
         if (__ballot(active && !done) == 0ull) break;
+        if (active && !done) l = pure_eval(c, rl);
     }
     if (done) return ST_OK;
     return ST_RETRY;  // includes cap hit: let the robust path decide
@@ -236,32 +252,33 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
     for (int it = 0; it < 100; it++) {
         Eval l = pure_eval(c, rl);
         Eval v = pure_eval(c, rv);
-        double p_star = -(v.a / rv - l.a / rl + log(rv / rl)) / (1.0 / rv - 1.0 / rl);
-        double dl = -(l.p - p_star) / l.dp;
-        double dv = -(v.p - p_star) / v.dp;
+        VleStep s = vle_step(l, v, rl, rv);
+        double dl = s.dl, dv = s.dv;
         double rl_new = rl + dl, rv_new = rv + dv;
+        bool damped = false;
         for (int k = 0; k < 40; k++) {
             if (rl_new > 0.0 && pure_eval(c, rl_new).dp > 0.0) break;
             dl *= 0.5;
             rl_new = rl + dl;
+            damped = true;
         }
         for (int k = 0; k < 40; k++) {
             if (rv_new > 0.0 && pure_eval(c, rv_new).dp > 0.0) break;
             dv *= 0.5;
             rv_new = rv + dv;
+            damped = true;
         }
         double err = fmax(fabs(dl) / rl, fabs(dv) / rv);
-        out.rho_v = rv;
-        out.rho_l = rl;
-        out.rho_l_new = rl_new;
-        out.p_star = p_star;
-        out.iters = it + 1;
         rl = rl_new;
         rv = rv_new;
+        out.rho_v = rv;
+        out.rho_l = rl;
+        out.p_star = s.p_corr;
+        out.iters = it + 1;
         if (!(rl == rl) || !(rv == rv)) return ST_FAILED;
         bool stagnated = it >= 3 && err < 1e-7 && err >= 0.25 * err_prev;
         err_prev = err;
-        if (err <= TOL_STEP || stagnated) {
+        if (!damped && (err <= TOL_STEP || stagnated)) {
             if (!(rv < rl * (1.0 - 1e-6))) return ST_FAILED;  // trivial solution
             return ST_OK;
         }

@@ -74,7 +74,7 @@ int pcs_pure_vle_retry(const double* params, const double* temp, int64_t n, doub
  * PcSaftPure.liquid_density (feos_torch/pcsaft_pure.py:184-199).
  *   pressure [n]  in   Pa
  *   rho_out  [n]  out  kmol/m3  (optional)  pcsaft_pure.py:198-199
- *   rho_root [n]  out  A^-3 density at which the final Newton step was taken (optional)
+ *   rho_root [n]  out  A^-3 converged density (the reference's rho of src/pcsaft.rs:127) (optional)
  */
 int pcs_pure_liquid_density(const double* params, const double* temp, const double* pressure, int64_t n,
                             double* rho_out, double* rho_root, uint8_t* status, void* stream);
