@@ -197,6 +197,95 @@ template <class T, int N> PCS_DEV HD<T, N> d_cbrt(const HD<T, N>& a) {
     return a.chain(s, f1, f1 * rx * (-2.0 / 3.0));
 }
 
+// =========================================================================================
+// T2<T>: second-order Taylor coefficients in TWO variables (the partial densities rho_1, rho_2):
+//        v, g[2] = d/drho_i, h[3] = d2/drho_1^2, d2/drho_1 drho_2, d2/drho_2^2.
+// Carries everything the bubble/dew Newton needs (chemical potentials, pressure and their full
+// Jacobian); the reference's DualTensor (dual_torch.py:4-158) carries only the V-mixed part.
+// =========================================================================================
+template <class T>
+struct T2 {
+    T v, g0, g1, h00, h01, h11;
+    PCS_DEV T2() {}
+    PCS_DEV T2(double x) : v(x), g0(0.0), g1(0.0), h00(0.0), h01(0.0), h11(0.0) {}
+    PCS_DEV T2(const T& a, const T& b, const T& c, const T& d, const T& e, const T& f) : v(a), g0(b), g1(c), h00(d), h01(e), h11(f) {}
+    // f(u): value f0, f' = f1, f'' = f2
+    PCS_DEV T2 chain(const T& f0, const T& f1, const T& f2) const {
+        return T2(f0, f1 * g0, f1 * g1, f1 * h00 + f2 * (g0 * g0), f1 * h01 + f2 * (g0 * g1), f1 * h11 + f2 * (g1 * g1));
+    }
+};
+template <class T> struct is_dual<T2<T>> { static constexpr bool value = true; };
+template <class T> PCS_DEV double re(const T2<T>& a) { return re(a.v); }
+template <class T> PCS_DEV T2<T> operator+(const T2<T>& a, const T2<T>& b) { return T2<T>(a.v + b.v, a.g0 + b.g0, a.g1 + b.g1, a.h00 + b.h00, a.h01 + b.h01, a.h11 + b.h11); }
+template <class T> PCS_DEV T2<T> operator-(const T2<T>& a, const T2<T>& b) { return T2<T>(a.v - b.v, a.g0 - b.g0, a.g1 - b.g1, a.h00 - b.h00, a.h01 - b.h01, a.h11 - b.h11); }
+template <class T> PCS_DEV T2<T> operator-(const T2<T>& a) { return T2<T>(-a.v, -a.g0, -a.g1, -a.h00, -a.h01, -a.h11); }
+template <class T> PCS_DEV T2<T> operator*(const T2<T>& a, const T2<T>& b) {
+    return T2<T>(a.v * b.v, a.g0 * b.v + a.v * b.g0, a.g1 * b.v + a.v * b.g1,
+                 a.h00 * b.v + 2.0 * (a.g0 * b.g0) + a.v * b.h00,
+                 a.h01 * b.v + a.g0 * b.g1 + a.g1 * b.g0 + a.v * b.h01,
+                 a.h11 * b.v + 2.0 * (a.g1 * b.g1) + a.v * b.h11);
+}
+template <class T> PCS_DEV T2<T> operator+(const T2<T>& a, double b) { T2<T> r = a; r.v = a.v + b; return r; }
+template <class T> PCS_DEV T2<T> operator+(double b, const T2<T>& a) { T2<T> r = a; r.v = a.v + b; return r; }
+template <class T> PCS_DEV T2<T> operator-(const T2<T>& a, double b) { T2<T> r = a; r.v = a.v - b; return r; }
+template <class T> PCS_DEV T2<T> operator-(double b, const T2<T>& a) { T2<T> r = -a; r.v = b - a.v; return r; }
+template <class T> PCS_DEV T2<T> operator*(const T2<T>& a, double b) { return T2<T>(a.v * b, a.g0 * b, a.g1 * b, a.h00 * b, a.h01 * b, a.h11 * b); }
+template <class T> PCS_DEV T2<T> operator*(double b, const T2<T>& a) { return a * b; }
+template <class T> PCS_DEV T2<T> d_recip(const T2<T>& a) { T r = d_recip(a.v); T r2 = r * r; return a.chain(r, -r2, 2.0 * (r2 * r)); }
+template <class T> PCS_DEV T2<T> operator/(const T2<T>& a, const T2<T>& b) { return a * d_recip(b); }
+template <class T> PCS_DEV T2<T> operator/(const T2<T>& a, double b) { double r = 1.0 / b; return a * r; }
+template <class T> PCS_DEV T2<T> operator/(double b, const T2<T>& a) { return d_recip(a) * b; }
+template <class T> PCS_DEV T2<T> d_log(const T2<T>& a) { T r = d_recip(a.v); return a.chain(d_log(a.v), r, -(r * r)); }
+template <class T> PCS_DEV T2<T> d_exp(const T2<T>& a) { T e = d_exp(a.v); return a.chain(e, e, e); }
+template <class T> PCS_DEV T2<T> d_sqrt(const T2<T>& a) { T s = d_sqrt(a.v); T h = 0.5 * d_recip(s); return a.chain(s, h, -(h * d_recip(a.v)) * 0.5); }
+template <class T> PCS_DEV T2<T> d_cbrt(const T2<T>& a) { T s = d_cbrt(a.v); T rx = d_recip(a.v); T f1 = s * rx * (1.0 / 3.0); return a.chain(s, f1, f1 * rx * (-2.0 / 3.0)); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T2<T> operator*(const T2<T>& a, const T& b) { return T2<T>(a.v * b, a.g0 * b, a.g1 * b, a.h00 * b, a.h01 * b, a.h11 * b); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T2<T> operator*(const T& b, const T2<T>& a) { return a * b; }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T2<T> operator+(const T2<T>& a, const T& b) { T2<T> r = a; r.v = a.v + b; return r; }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T2<T> operator+(const T& b, const T2<T>& a) { T2<T> r = a; r.v = a.v + b; return r; }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T2<T> operator-(const T2<T>& a, const T& b) { T2<T> r = a; r.v = a.v - b; return r; }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T2<T> operator-(const T& b, const T2<T>& a) { T2<T> r = -a; r.v = b - a.v; return r; }
+
+// =========================================================================================
+// T1<T>: first-order Taylor coefficients in the two partial densities (v, g0, g1).  With
+// T = DN<double,C> it carries d(a, da/drho_i)/d(parameter) — what the implicit-function
+// gradients of the bubble/dew pressure need.
+// =========================================================================================
+template <class T>
+struct T1 {
+    T v, g0, g1;
+    PCS_DEV T1() {}
+    PCS_DEV T1(double x) : v(x), g0(0.0), g1(0.0) {}
+    PCS_DEV T1(const T& a, const T& b, const T& c) : v(a), g0(b), g1(c) {}
+    PCS_DEV T1 chain(const T& f0, const T& f1) const { return T1(f0, f1 * g0, f1 * g1); }
+};
+template <class T> struct is_dual<T1<T>> { static constexpr bool value = true; };
+template <class T> PCS_DEV double re(const T1<T>& a) { return re(a.v); }
+template <class T> PCS_DEV T1<T> operator+(const T1<T>& a, const T1<T>& b) { return T1<T>(a.v + b.v, a.g0 + b.g0, a.g1 + b.g1); }
+template <class T> PCS_DEV T1<T> operator-(const T1<T>& a, const T1<T>& b) { return T1<T>(a.v - b.v, a.g0 - b.g0, a.g1 - b.g1); }
+template <class T> PCS_DEV T1<T> operator-(const T1<T>& a) { return T1<T>(-a.v, -a.g0, -a.g1); }
+template <class T> PCS_DEV T1<T> operator*(const T1<T>& a, const T1<T>& b) { return T1<T>(a.v * b.v, a.g0 * b.v + a.v * b.g0, a.g1 * b.v + a.v * b.g1); }
+template <class T> PCS_DEV T1<T> operator+(const T1<T>& a, double b) { return T1<T>(a.v + b, a.g0, a.g1); }
+template <class T> PCS_DEV T1<T> operator+(double b, const T1<T>& a) { return T1<T>(a.v + b, a.g0, a.g1); }
+template <class T> PCS_DEV T1<T> operator-(const T1<T>& a, double b) { return T1<T>(a.v - b, a.g0, a.g1); }
+template <class T> PCS_DEV T1<T> operator-(double b, const T1<T>& a) { return T1<T>(b - a.v, -a.g0, -a.g1); }
+template <class T> PCS_DEV T1<T> operator*(const T1<T>& a, double b) { return T1<T>(a.v * b, a.g0 * b, a.g1 * b); }
+template <class T> PCS_DEV T1<T> operator*(double b, const T1<T>& a) { return a * b; }
+template <class T> PCS_DEV T1<T> d_recip(const T1<T>& a) { T r = d_recip(a.v); return a.chain(r, -(r * r)); }
+template <class T> PCS_DEV T1<T> operator/(const T1<T>& a, const T1<T>& b) { return a * d_recip(b); }
+template <class T> PCS_DEV T1<T> operator/(const T1<T>& a, double b) { double r = 1.0 / b; return a * r; }
+template <class T> PCS_DEV T1<T> operator/(double b, const T1<T>& a) { return d_recip(a) * b; }
+template <class T> PCS_DEV T1<T> d_log(const T1<T>& a) { return a.chain(d_log(a.v), d_recip(a.v)); }
+template <class T> PCS_DEV T1<T> d_exp(const T1<T>& a) { T e = d_exp(a.v); return a.chain(e, e); }
+template <class T> PCS_DEV T1<T> d_sqrt(const T1<T>& a) { T s = d_sqrt(a.v); return a.chain(s, 0.5 * d_recip(s)); }
+template <class T> PCS_DEV T1<T> d_cbrt(const T1<T>& a) { T s = d_cbrt(a.v); return a.chain(s, s * d_recip(a.v) * (1.0 / 3.0)); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator*(const T1<T>& a, const T& b) { return T1<T>(a.v * b, a.g0 * b, a.g1 * b); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator*(const T& b, const T1<T>& a) { return a * b; }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator+(const T1<T>& a, const T& b) { return T1<T>(a.v + b, a.g0, a.g1); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator+(const T& b, const T1<T>& a) { return T1<T>(a.v + b, a.g0, a.g1); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator-(const T1<T>& a, const T& b) { return T1<T>(a.v - b, a.g0, a.g1); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator-(const T& b, const T1<T>& a) { return T1<T>(b - a.v, -a.g0, -a.g1); }
+
 // ---- lifting a parameter-type value P into a result type R -------------------------------
 // Model code is templated on <P, R>: P is the type of parameters / temperature-only
 // coefficients (double in the solvers, a dual in the gradient kernels), R the type of the
@@ -205,6 +294,8 @@ template <class R, class P> struct Lift;
 template <class R> struct Lift<R, R> { static PCS_DEV const R& go(const R& p) { return p; } };
 template <class T> struct Lift<D2<T>, double> { static PCS_DEV D2<T> go(double p) { return D2<T>(p); } };
 template <class T, int N> struct Lift<DN<T, N>, double> { static PCS_DEV DN<T, N> go(double p) { return DN<T, N>(p); } };
+template <class T> struct Lift<T1<T>, T> { static PCS_DEV T1<T> go(const T& p) { return T1<T>(p, T(0.0), T(0.0)); } };
+template <class T> struct Lift<T2<T>, double> { static PCS_DEV T2<T> go(double p) { return T2<T>(p); } };
 template <class T, int N> struct Lift<HD<T, N>, double> { static PCS_DEV HD<T, N> go(double p) { return HD<T, N>(p); } };
 
 }  // namespace pcs

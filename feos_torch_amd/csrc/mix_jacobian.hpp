@@ -1,0 +1,106 @@
+// Gradient of the bubble / dew pressure w.r.t. (16 component parameters, k_ij, eps_AiBj, T) for
+// binary mixtures (device only).
+//
+// The reference gets it by torch reverse mode through its explicit final Newton step
+// (feos_torch/pcsaft_mix.py:435-444 / :459-468), constructed so that the result equals the
+// implicit-function derivative of the converged pressure.  Here the implicit-function theorem is
+// applied directly at the converged state u = (ln rho_spec, ln rho_inc_0, ln rho_inc_1):
+//     F(u, theta) = (mu_0^S - mu_0^I, mu_1^S - mu_1^I, p^S - p^I) = 0,   p = p^S(u, theta)
+//     dp/dtheta = dp^vap/dtheta|_u - w . dF/dtheta|_u,      J^T w = dp^vap/du   (vap = vapour phase)
+// J comes from one T2<double> evaluation per phase (as in the solver); the explicit parameter
+// derivatives d(a, da/drho_i)/dtheta from T1<DN<double,C>> evaluations, C directions per pass.
+#pragma once
+#include "mix_model.hpp"
+#include "mix_solver.hpp"
+
+namespace pcs {
+
+constexpr int MIX_DIRS = 19;  // 16 parameters (component 0 then 1), k_ij, eps_AiBj, T
+constexpr int MIX_CHUNK = 2;
+
+struct MixModelD {
+    MixCoef<double> c;
+    template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return mix_a<double, R>(c, r0, r1); }
+    PCS_DEV double packing(double x0, double x1) const { return x0 * c.zk[3][0] + x1 * c.zk[3][1]; }
+};
+
+// spec = (rho_spec_0, rho_spec_1), inc = (rho_inc_0, rho_inc_1); out[19] in Pa per unit of theta
+// spec_is_vapor: the pressure functional is always taken on the VAPOUR phase (p^S for dew, p^I for
+// bubble): the liquid-phase pressure is a difference of O(0.1) terms, so its explicit parameter
+// derivative would have to cancel against w . dF/dtheta to the size of p itself.
+PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, double s0, double s1, double i0,
+                          double i1, bool spec_is_vapor, double g[MIX_DIRS]) {
+    MixModelD m;
+    mix_coef<double>(m.c, par, k0, k1, T);
+    PhaseEval s = phase_eval(m, s0, s1);
+    PhaseEval n = phase_eval(m, i0, i1);
+    const double rs = s0 + s1, z0 = s0 / rs, z1 = s1 / rs;
+    // transposed Jacobian of F w.r.t. u, right-hand side dp^S/du = (rs (z0 dp0 + z1 dp1), 0, 0)
+    double J[3][3];
+    J[0][0] = rs * (z0 * (1.0 / s.r0 + s.h00) + z1 * s.h01);
+    J[1][0] = rs * (z0 * s.h01 + z1 * (1.0 / s.r1 + s.h11));
+    J[2][0] = rs * (z0 * s.dp0() + z1 * s.dp1());
+    J[0][1] = -i0 * (1.0 / i0 + n.h00);
+    J[1][1] = -i0 * n.h01;
+    J[2][1] = -i0 * n.dp0();
+    J[0][2] = -i1 * n.h01;
+    J[1][2] = -i1 * (1.0 / i1 + n.h11);
+    J[2][2] = -i1 * n.dp1();
+    double A[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) A[r][cc] = J[cc][r];  // J^T
+        A[r][3] = 0.0;
+    }
+    if (spec_is_vapor) {
+        A[0][3] = J[2][0];  // dp^S/du = (rs (z0 dp0 + z1 dp1), 0, 0)
+    } else {
+        A[1][3] = -J[2][1];  // dp^I/du = (0, i0 dp0^I, i1 dp1^I)
+        A[2][3] = -J[2][2];
+    }
+    double w[3];
+    bool ok = solve3(A, w);
+    const double p_red = spec_is_vapor ? s.p() : n.p();
+    typedef DN<double, MIX_CHUNK> G;
+    typedef T1<G> R;
+    constexpr int NPASS = (MIX_DIRS + MIX_CHUNK - 1) / MIX_CHUNK;
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; pass++) {
+        const int d0 = pass * MIX_CHUNK;
+        G gp[16], gk0, gk1, gT;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            gp[k].v = par[k];
+#pragma unroll
+            for (int j = 0; j < MIX_CHUNK; j++) gp[k].e[j] = (d0 + j == k) ? 1.0 : 0.0;
+        }
+        gk0.v = k0; gk1.v = k1; gT.v = T;
+#pragma unroll
+        for (int j = 0; j < MIX_CHUNK; j++) {
+            gk0.e[j] = (d0 + j == 16) ? 1.0 : 0.0;
+            gk1.e[j] = (d0 + j == 17) ? 1.0 : 0.0;
+            gT.e[j] = (d0 + j == 18) ? 1.0 : 0.0;
+        }
+        MixCoef<G> c;
+        mix_coef<G>(c, gp, gk0, gk1, gT);
+        R aS = mix_a<G, R>(c, R(G(s0), G(1.0), G(0.0)), R(G(s1), G(0.0), G(1.0)));
+        R aI = mix_a<G, R>(c, R(G(i0), G(1.0), G(0.0)), R(G(i1), G(0.0), G(1.0)));
+#pragma unroll
+        for (int j = 0; j < MIX_CHUNK; j++) {
+            double dF0 = aS.g0.e[j] - aI.g0.e[j];
+            double dF1 = aS.g1.e[j] - aI.g1.e[j];
+            double dpS = -aS.v.e[j] + s0 * aS.g0.e[j] + s1 * aS.g1.e[j];
+            double dpI = -aI.v.e[j] + i0 * aI.g0.e[j] + i1 * aI.g1.e[j];
+            double dp = (spec_is_vapor ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
+            double val = dp * T * P_UNIT;
+            if (d0 + j == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
+            if (!ok) val = __builtin_nan("");
+#pragma unroll
+            for (int d = 0; d < MIX_DIRS; d++)
+                if (d == d0 + j) g[d] = val;
+        }
+    }
+}
+
+}  // namespace pcs

@@ -1,0 +1,168 @@
+// gfx950 kernels + C ABI for the binary-mixture PC-SAFT path (bubble / dew points,
+// PcSaftMix.derivatives).  One state point per lane; see pure_kernels.hip for the launch-shape
+// rationale.  Per-row inputs: parameters [n,2,8] (128 B AoS, read with four 16-byte loads per
+// component row), kij [n,2], T, z, p_init — 168 B read, 8 B + 32 B + 1 B written per row against
+// ~1e5 fp64 operations: compute bound by three orders of magnitude.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pcsaft_hip.h"
+#include "abi_common.hpp"
+#include "mix_model.hpp"
+#include "mix_solver.hpp"
+#include "mix_jacobian.hpp"
+
+using namespace pcs;
+using namespace pcs_abi;
+
+namespace {
+
+constexpr int MBLOCK = 128;
+
+struct MixModel {
+    MixCoef<double> c;
+    template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return mix_a<double, R>(c, r0, r1); }
+    PCS_DEV double packing(double x0, double x1) const { return x0 * c.zk[3][0] + x1 * c.zk[3][1]; }
+};
+
+__device__ __forceinline__ void load_mix_row(const double* __restrict__ params, const double* __restrict__ kij,
+                                             int64_t i, double par[16], double& k0, double& k1) {
+    const double2* src = reinterpret_cast<const double2*>(params + 16 * i);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        double2 v = src[k];
+        par[2 * k] = v.x;
+        par[2 * k + 1] = v.y;
+    }
+    double2 kk = reinterpret_cast<const double2*>(kij)[i];
+    k0 = kk.x;
+    k1 = kk.y;
+}
+
+template <bool DEW>
+__global__ __launch_bounds__(MBLOCK) void k_mix_bubble_dew(const double* __restrict__ params,
+                                                           const double* __restrict__ kij,
+                                                           const double* __restrict__ temp,
+                                                           const double* __restrict__ z,
+                                                           const double* __restrict__ p_init, int64_t n,
+                                                           double* __restrict__ p_out, double* __restrict__ rho4,
+                                                           uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
+    const int64_t i = (int64_t)blockIdx.x * MBLOCK + threadIdx.x;
+    if (i >= n) return;
+    double par[16], k0, k1;
+    load_mix_row(params, kij, i, par, k0, k1);
+    const double T = temp[i];
+    MixModel m;
+    mix_coef<double>(m.c, par, k0, k1, T);
+    MixResult r;
+    const double p_red = p_init[i] / (T * P_UNIT);
+    bool ok = bubble_dew_solve<DEW>(m, z[i], p_red, r);
+    if (p_out) p_out[i] = ok ? r.p * T * P_UNIT : 0.0;
+    if (rho4) {
+        // reference layout (src/pcsaft.rs:225-228): [rhoV_1, rhoV_2, rhoL_1, rhoL_2]
+        double v0 = DEW ? r.spec0 : r.inc0, v1 = DEW ? r.spec1 : r.inc1;
+        double l0 = DEW ? r.inc0 : r.spec0, l1 = DEW ? r.inc1 : r.spec1;
+        double4 o = ok ? make_double4(v0, v1, l0, l1) : make_double4(0.0, 0.0, 0.0, 0.0);
+        reinterpret_cast<double4*>(rho4)[i] = o;
+    }
+    if (iters) iters[i] = ok ? r.iters : -1;
+    status[i] = ok ? 0 : 1;
+}
+
+// PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420): a, p, mu_i, v_i at given partial densities
+__global__ __launch_bounds__(MBLOCK) void k_mix_derivatives(const double* __restrict__ params,
+                                                            const double* __restrict__ kij,
+                                                            const double* __restrict__ temp,
+                                                            const double* __restrict__ rho, int64_t n,
+                                                            double* __restrict__ a, double* __restrict__ p,
+                                                            double* __restrict__ mu, double* __restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * MBLOCK + threadIdx.x;
+    if (i >= n) return;
+    double par[16], k0, k1;
+    load_mix_row(params, kij, i, par, k0, k1);
+    MixModel m;
+    mix_coef<double>(m.c, par, k0, k1, temp[i]);
+    PhaseEval e = phase_eval(m, rho[2 * i], rho[2 * i + 1]);
+    if (a) a[i] = e.a;
+    if (p) p[i] = e.p();
+    if (mu) { mu[2 * i] = e.g0; mu[2 * i + 1] = e.g1; }
+    if (v) {
+        double d0 = e.dp0(), d1 = e.dp1();
+        double den = 1.0 / (e.r0 * d0 + e.r1 * d1);
+        v[2 * i] = d0 * den;
+        v[2 * i + 1] = d1 * den;
+    }
+}
+
+// K6: gradient of the bubble / dew pressure at the converged densities
+__global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* __restrict__ params,
+                                                         const double* __restrict__ kij,
+                                                         const double* __restrict__ temp,
+                                                         const double* __restrict__ rho4, int64_t n,
+                                                         double* __restrict__ jac) {
+    const int64_t i = (int64_t)blockIdx.x * MBLOCK + threadIdx.x;
+    if (i >= n) return;
+    double par[16], k0, k1;
+    load_mix_row(params, kij, i, par, k0, k1);
+    double4 r = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
+    double g[MIX_DIRS];
+    if (dew) mix_jacobian(par, k0, k1, temp[i], r.x, r.y, r.z, r.w, true, g);
+    else mix_jacobian(par, k0, k1, temp[i], r.z, r.w, r.x, r.y, false, g);
+#pragma unroll
+    for (int k = 0; k < MIX_DIRS; k++) jac[MIX_DIRS * i + k] = g[k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const double* temp, const double* z,
+                       const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status, int32_t* iters,
+                       void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !kij || !temp || !z || !p_init || !status) return fail_msg("pcs_mix_bubble_dew: null required pointer");
+    const unsigned grid = (unsigned)((n + MBLOCK - 1) / MBLOCK);
+    hipStream_t s = as_stream(stream);
+    if (dew)
+        hipLaunchKernelGGL(k_mix_bubble_dew<true>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
+                           rho4, status, iters);
+    else
+        hipLaunchKernelGGL(k_mix_bubble_dew<false>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
+                           rho4, status, iters);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_mix_bubble_dew launch", e);
+    return 0;
+}
+
+int pcs_mix_derivatives(const double* params, const double* kij, const double* temp, const double* rho, int64_t n,
+                        double* a, double* p, double* mu, double* v, void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !kij || !temp || !rho) return fail_msg("pcs_mix_derivatives: null required pointer");
+    const unsigned grid = (unsigned)((n + MBLOCK - 1) / MBLOCK);
+    hipLaunchKernelGGL(k_mix_derivatives, dim3(grid), dim3(MBLOCK), 0, as_stream(stream), params, kij,
+                       temp, rho, n, a, p, mu, v);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_mix_derivatives launch", e);
+    return 0;
+}
+
+int pcs_mix_jacobian(int dew, const double* params, const double* kij, const double* temp, const double* rho4,
+                     int64_t n, double* jac, void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !kij || !temp || !rho4 || !jac) return fail_msg("pcs_mix_jacobian: null required pointer");
+    const unsigned grid = (unsigned)((n + MBLOCK - 1) / MBLOCK);
+    hipLaunchKernelGGL(k_mix_jacobian, dim3(grid), dim3(MBLOCK), 0, as_stream(stream), dew, params, kij, temp, rho4, n,
+                       jac);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_mix_jacobian launch", e);
+    return 0;
+}
+
+}  // extern "C"

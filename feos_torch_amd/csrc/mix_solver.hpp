@@ -1,0 +1,222 @@
+// Per-lane bubble- / dew-point solver for binary mixtures (device only).
+//
+// Stands where the reference calls feos' PhaseEquilibrium::bubble_point / dew_point per row
+// (src/pcsaft.rs:150-214, src/gc_pcsaft.rs:103-171).  Problem: at fixed T and composition z of
+// the SPECIFIED phase (liquid for bubble, vapour for dew) find rho^spec (total) and the partial
+// densities rho^inc_1,2 of the incipient phase with equal chemical potentials and pressure:
+//     mu_i = ln rho_i + da/drho_i,     p = sum rho - a + sum rho_k da/drho_k        (reduced)
+// Newton in the logarithms of the three unknowns with the full analytic Jacobian from one
+// T2<double> evaluation per phase.  Initialisation: bubble — liquid root at the caller's initial
+// pressure, ideal vapour at the liquid's fugacities; dew — Raoult's law from zero-pressure pure-
+// liquid fugacities, refined by ideal-vapour successive substitution.
+// The returned pressure is the reference's final explicit Newton step (feos_torch/
+// pcsaft_mix.py:435-444 / :459-468) evaluated at the converged densities.
+//
+// `Model` = a coefficient struct with  template<class R> R a(const R& r0, const R& r1) const  and
+// packing(x0, x1) = zeta3 / rho_total.  Shared by PcSaftMix and GcPcSaftMix kernels.
+#pragma once
+#include "dual.hpp"
+#include "pcsaft_consts.hpp"
+
+namespace pcs {
+
+struct PhaseEval {
+    double r0, r1;
+    double a, g0, g1, h00, h01, h11;
+    PCS_DEV double mu0() const { return log(r0) + g0; }
+    PCS_DEV double mu1() const { return log(r1) + g1; }
+    PCS_DEV double p() const { return r0 + r1 - a + r0 * g0 + r1 * g1; }
+    PCS_DEV double dp0() const { return 1.0 + r0 * h00 + r1 * h01; }  // dp/drho_0
+    PCS_DEV double dp1() const { return 1.0 + r0 * h01 + r1 * h11; }
+};
+
+template <class Model>
+PCS_DEV PhaseEval phase_eval(const Model& m, double r0, double r1) {
+    typedef T2<double> R;
+    R a = m.template a<R>(R(r0, 1.0, 0.0, 0.0, 0.0, 0.0), R(r1, 0.0, 1.0, 0.0, 0.0, 0.0));
+    PhaseEval e;
+    e.r0 = r0; e.r1 = r1;
+    e.a = a.v; e.g0 = a.g0; e.g1 = a.g1; e.h00 = a.h00; e.h01 = a.h01; e.h11 = a.h11;
+    return e;
+}
+
+// p and dp/drho along a fixed composition (x0, x1): one D2 evaluation
+template <class Model>
+PCS_DEV void line_eval(const Model& m, double x0, double x1, double rho, double& p, double& dp, double& a) {
+    typedef D2<double> R;
+    R r = m.template a<R>(R(x0 * rho, x0, 0.0), R(x1 * rho, x1, 0.0));
+    a = r.v;
+    p = rho - r.v + rho * r.d1;
+    dp = 1.0 + rho * r.d2;
+}
+
+// liquid-like root of p(rho) = p_spec at composition x from the dense side
+template <class Model>
+PCS_DEV bool liquid_root(const Model& m, double x0, double x1, double p_spec, double& rho_out) {
+    double pk = m.packing(x0, x1);
+    double rho = 0.5 / pk;
+    double err_prev = 1.0;
+    for (int it = 0; it < 60; it++) {
+        double p, dp, a;
+        line_eval(m, x0, x1, rho, p, dp, a);
+        if (it == 0 && !(p > p_spec)) {
+            rho = 0.62 / pk;
+            line_eval(m, x0, x1, rho, p, dp, a);
+        }
+        if (!(dp > 0.0) || !(p == p)) return false;
+        double step = (p - p_spec) / dp;
+        double rho_new = rho - step;
+        if (!(rho_new > 0.0)) return false;
+        double err = fabs(step) / rho;
+        bool done = err <= 1e-10 || (it >= 3 && err < 1e-7 && err >= 0.25 * err_prev);
+        err_prev = err;
+        rho = rho_new;
+        if (done) {
+            rho_out = rho;
+            return true;
+        }
+    }
+    return false;
+}
+
+// 3x3 linear solve, Gaussian elimination with partial pivoting; all indices static so the
+// augmented matrix stays in registers (runtime-indexed local arrays would go to scratch).
+PCS_DEV void swap_rows(double* a, double* b) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { double t = a[j]; a[j] = b[j]; b[j] = t; }
+}
+PCS_DEV bool solve3(double A[3][4], double* x) {
+    if (fabs(A[1][0]) > fabs(A[0][0])) swap_rows(A[0], A[1]);
+    if (fabs(A[2][0]) > fabs(A[0][0])) swap_rows(A[0], A[2]);
+    if (A[0][0] == 0.0) return false;
+    double inv = 1.0 / A[0][0];
+    double f1 = A[1][0] * inv, f2 = A[2][0] * inv;
+#pragma unroll
+    for (int j = 1; j < 4; j++) { A[1][j] -= f1 * A[0][j]; A[2][j] -= f2 * A[0][j]; }
+    if (fabs(A[2][1]) > fabs(A[1][1])) swap_rows(A[1], A[2]);
+    if (A[1][1] == 0.0) return false;
+    double f = A[2][1] / A[1][1];
+    A[2][2] -= f * A[1][2];
+    A[2][3] -= f * A[1][3];
+    if (A[2][2] == 0.0) return false;
+    x[2] = A[2][3] / A[2][2];
+    x[1] = (A[1][3] - A[1][2] * x[2]) / A[1][1];
+    x[0] = (A[0][3] - A[0][1] * x[1] - A[0][2] * x[2]) * inv;
+    return true;
+}
+
+struct MixResult {
+    double spec0, spec1, inc0, inc1;  // converged partial densities
+    double p;                         // reduced pressure from the reference's final formula
+    int iters;
+};
+
+// the reference's final formula (pcsaft_mix.py:435-444 with spec = liquid, inc = vapour; :459-468
+// with the roles swapped): p = -(a_inc/rho_inc + p_spec v + g - 1) / (1/rho_inc - v)
+PCS_DEV double bubble_dew_formula(const PhaseEval& s, const PhaseEval& n) {
+    double rho_i = n.r0 + n.r1;
+    double y0 = n.r0 / rho_i, y1 = n.r1 / rho_i;
+    // partial molar volumes of the specified phase: v_i = (dp/drho_i) / sum_j rho_j dp/drho_j  (:416-418)
+    double d0 = s.dp0(), d1 = s.dp1();
+    double den = 1.0 / (s.r0 * d0 + s.r1 * d1);
+    double v = (y0 * d0 + y1 * d1) * den;
+    double g = y0 * (log(n.r0 / s.r0) - s.g0) + y1 * (log(n.r1 / s.r1) - s.g1);
+    return -(n.a / rho_i + s.p() * v + g - 1.0) / (1.0 / rho_i - v);
+}
+
+template <bool DEW, class Model>
+PCS_DEV bool bubble_dew_solve(const Model& m, double z0, double p_init, MixResult& out) {
+    const double z1 = 1.0 - z0;
+    double rs, ri0, ri1;
+    out.iters = 0;
+    if (!DEW) {
+        if (!liquid_root(m, z0, z1, p_init, rs) && !liquid_root(m, z0, z1, 0.0, rs)) return false;
+        PhaseEval e = phase_eval(m, z0 * rs, z1 * rs);
+        ri0 = e.r0 * exp(e.g0);
+        ri1 = e.r1 * exp(e.g1);
+    } else {
+        double f[2];
+        bool ok = true;
+#pragma unroll 1
+        for (int i = 0; i < 2; i++) {
+            double x0 = (i == 0) ? 1.0 : 0.0, x1 = 1.0 - x0, rho0;
+            if (!liquid_root(m, x0, x1, 0.0, rho0)) { ok = false; break; }
+            PhaseEval e = phase_eval(m, x0 * rho0, x1 * rho0);
+            f[i] = rho0 * exp(i == 0 ? e.g0 : e.g1);
+        }
+        double x0, x1, p0;
+        if (ok) {
+            p0 = 1.0 / (z0 / f[0] + z1 / f[1]);
+            x0 = z0 * p0 / f[0];
+            x1 = z1 * p0 / f[1];
+        } else {
+            p0 = p_init;
+            x0 = z0;
+            x1 = z1;
+        }
+        double rl = 0.0;
+        for (int ss = 0; ss < 200; ss++) {
+            if (!liquid_root(m, x0, x1, 0.0, rl) && !liquid_root(m, x0, x1, p0, rl)) return false;
+            PhaseEval e = phase_eval(m, x0 * rl, x1 * rl);
+            double w0 = z0 * x0 / (e.r0 * exp(e.g0)), w1 = z1 * x1 / (e.r1 * exp(e.g1));
+            double sum = w0 + w1;
+            double n0 = w0 / sum, n1 = w1 / sum;
+            double dx = fabs(n0 - x0);
+            n0 = fmin(fmax(n0, 0.2 * x0), 5.0 * x0);
+            n1 = fmin(fmax(n1, 0.2 * x1), 5.0 * x1);
+            double s2 = n0 + n1;
+            x0 = n0 / s2;
+            x1 = n1 / s2;
+            p0 = 1.0 / sum;
+            if (dx < 1e-7) break;
+        }
+        if (!liquid_root(m, x0, x1, p0, rl) && !liquid_root(m, x0, x1, 0.0, rl)) return false;
+        ri0 = x0 * rl;
+        ri1 = x1 * rl;
+        rs = p0;
+    }
+    double err_prev = 1.0;
+    for (int it = 0; it < 200; it++) {
+        PhaseEval s = phase_eval(m, z0 * rs, z1 * rs);
+        PhaseEval n = phase_eval(m, ri0, ri1);
+        double A[3][4];
+        // rows: mu_0, mu_1, p;  columns: ln rho_spec, ln rho_inc_0, ln rho_inc_1
+        A[0][0] = rs * (z0 * (1.0 / s.r0 + s.h00) + z1 * s.h01);
+        A[1][0] = rs * (z0 * s.h01 + z1 * (1.0 / s.r1 + s.h11));
+        A[2][0] = rs * (z0 * s.dp0() + z1 * s.dp1());
+        A[0][1] = -ri0 * (1.0 / ri0 + n.h00);
+        A[1][1] = -ri0 * n.h01;
+        A[2][1] = -ri0 * n.dp0();
+        A[0][2] = -ri1 * n.h01;
+        A[1][2] = -ri1 * (1.0 / ri1 + n.h11);
+        A[2][2] = -ri1 * n.dp1();
+        A[0][3] = -(s.mu0() - n.mu0());
+        A[1][3] = -(s.mu1() - n.mu1());
+        A[2][3] = -(s.p() - n.p());
+        double du[3];
+        if (!solve3(A, du)) return false;
+        double mx = fmax(fabs(du[0]), fmax(fabs(du[1]), fabs(du[2])));
+        if (!(mx == mx)) return false;
+        double scale = mx > 1.0 ? 1.0 / mx : 1.0;  // at most a factor e per iteration
+        rs *= exp(scale * du[0]);
+        ri0 *= exp(scale * du[1]);
+        ri1 *= exp(scale * du[2]);
+        out.iters = it + 1;
+        bool stagnated = it >= 3 && mx < 1e-7 && mx >= 0.25 * err_prev;
+        err_prev = mx;
+        if (mx <= 1e-9 || stagnated) {
+            double dens_i = ri0 + ri1;
+            double lo = DEW ? rs : dens_i, hi = DEW ? dens_i : rs;
+            if (!(lo < hi * (1.0 - 1e-6))) return false;  // trivial solution
+            // final evaluation at the converged state -> reference formula
+            PhaseEval sf = phase_eval(m, z0 * rs, z1 * rs);
+            PhaseEval nf = phase_eval(m, ri0, ri1);
+            out.spec0 = sf.r0; out.spec1 = sf.r1; out.inc0 = ri0; out.inc1 = ri1;
+            out.p = bubble_dew_formula(sf, nf);
+            return out.p == out.p;
+        }
+    }
+    return false;
+}
+
+}  // namespace pcs

@@ -13,27 +13,20 @@
 #include <string.h>
 
 #include "../../include/pcsaft_hip.h"
+#include "abi_common.hpp"
 #include "pure_solver.hpp"
 #include "pure_jacobian.hpp"
 
 using namespace pcs;
+using namespace pcs_abi;
+
+thread_local char pcs_abi::g_err[256] = "";
 
 namespace {
 
 constexpr int BLOCK = 256;
 constexpr int RETRY_GRID = 1024;  // 64-thread workgroups of the robust pass
 constexpr int ROW_PAD = 9;  // doubles per staged row (8 + 1 pad): bank-conflict-free per-lane reads
-
-thread_local char g_err[256] = "";
-
-int fail(const char* what, hipError_t e) {
-    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
-    return 1;
-}
-int fail_msg(const char* what) {
-    snprintf(g_err, sizeof(g_err), "%s", what);
-    return 2;
-}
 
 // Cooperative, coalesced load of the workgroup's parameter rows into LDS, then one row per lane.
 // Rows past n are clamped to row n-1 (their results are never stored).
@@ -219,14 +212,6 @@ __global__ __launch_bounds__(BLOCK) void k_pure_jacobian(const double* __restric
     // a failed row carries zero densities -> NaNs; the caller masks by status
 #pragma unroll
     for (int k = 0; k < 10; k++) jac[10 * i + k] = g[k];
-}
-
-hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-int check_n(int64_t n) {
-    if (n < 0) return fail_msg("n must be >= 0");
-    if (n >= (int64_t)1 << 31) return fail_msg("n must be < 2^31 rows per call (shard larger batches)");
-    return 0;
 }
 
 }  // namespace

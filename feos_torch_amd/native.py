@@ -189,3 +189,92 @@ class PureVlePlan:
 
     def retry_count(self):
         return int(self.ws[0].item())
+
+
+# ------------------------------------------------------------------------------------------
+# binary mixtures
+# ------------------------------------------------------------------------------------------
+def mix_bubble_dew(params, kij, temperature, molefracs, pressure, dew, want_iters=False):
+    """Bubble (dew=False) / dew (dew=True) points.  -> dict(p [Pa], rho4 [n,4] A^-3 = (rhoV_1, rhoV_2,
+    rhoL_1, rhoL_2), status bool, iters)."""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    params = _prep(params, device, (2, 8))
+    kij = _prep(kij, device, (2,))
+    temperature = _prep(temperature, device)
+    molefracs = _prep(molefracs, device)
+    pressure = _prep(pressure, device)
+    n = temperature.shape[0]
+    if not (params.shape[0] == kij.shape[0] == molefracs.shape[0] == pressure.shape[0] == n):
+        raise ValueError("inputs differ in length")
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        p = torch.empty(n, dtype=_F64, device=device)
+        rho4 = torch.empty((n, 4), dtype=_F64, device=device)
+        status = torch.empty(n, dtype=torch.uint8, device=device)
+        iters = torch.empty(n, dtype=torch.int32, device=device) if want_iters else None
+        rc = L.pcs_mix_bubble_dew(int(bool(dew)), _lib.ptr(params), _lib.ptr(kij), _lib.ptr(temperature),
+                                  _lib.ptr(molefracs), _lib.ptr(pressure), n, _lib.ptr(p), _lib.ptr(rho4),
+                                  _lib.ptr(status), _lib.ptr(iters), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_mix_bubble_dew")
+    return {"p": p, "rho4": rho4, "status": status.bool(), "iters": iters}
+
+
+def mix_derivatives(params, kij, temperature, density):
+    """(a [n], p [n], mu [n,2], v [n,2]) — PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420)."""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    params = _prep(params, device, (2, 8))
+    kij = _prep(kij, device, (2,))
+    temperature = _prep(temperature, device)
+    density = _prep(density, device, (2,))
+    n = temperature.shape[0]
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        a = torch.empty(n, dtype=_F64, device=device)
+        p = torch.empty(n, dtype=_F64, device=device)
+        mu = torch.empty((n, 2), dtype=_F64, device=device)
+        v = torch.empty((n, 2), dtype=_F64, device=device)
+        rc = L.pcs_mix_derivatives(_lib.ptr(params), _lib.ptr(kij), _lib.ptr(temperature), _lib.ptr(density), n,
+                                   _lib.ptr(a), _lib.ptr(p), _lib.ptr(mu), _lib.ptr(v), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_mix_derivatives")
+    return a, p, mu, v
+
+
+def _pcsaft_bubble_dew(parameters, kij, temperature, molefracs, pressure, dew):
+    parameters = _as_f64(parameters, 3)
+    kij = _as_f64(kij, 2)
+    temperature, molefracs, pressure = _as_f64(temperature, 1), _as_f64(molefracs, 1), _as_f64(pressure, 1)
+    r = mix_bubble_dew(torch.from_numpy(parameters), torch.from_numpy(kij), torch.from_numpy(temperature),
+                       torch.from_numpy(molefracs), torch.from_numpy(pressure), dew)
+    status = r["status"].cpu().numpy()
+    return r["rho4"].cpu().numpy()[~status], status
+
+
+def _bubble_point(parameters, kij, temperature, liquid_molefracs, pressure):
+    """src/pcsaft.rs:43-60 — rho[n_ok, 4] = (rhoV_1, rhoV_2, rhoL_1, rhoL_2), status[N]."""
+    return _pcsaft_bubble_dew(parameters, kij, temperature, liquid_molefracs, pressure, False)
+
+
+def _dew_point(parameters, kij, temperature, vapor_molefracs, pressure):
+    """src/pcsaft.rs:62-79."""
+    return _pcsaft_bubble_dew(parameters, kij, temperature, vapor_molefracs, pressure, True)
+
+
+PcSaft.bubble_point = staticmethod(_bubble_point)
+PcSaft.dew_point = staticmethod(_dew_point)
+
+
+def mix_jacobian(params, kij, temperature, rho4, dew):
+    """[n,19] gradient of the bubble/dew pressure w.r.t. (params[0,:], params[1,:], kij[0], kij[1], T)."""
+    device = rho4.device
+    params = _prep(params, device, (2, 8))
+    kij = _prep(kij, device, (2,))
+    temperature = _prep(temperature, device)
+    rho4 = _prep(rho4, device, (4,))
+    n = temperature.shape[0]
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        jac = torch.empty((n, 19), dtype=_F64, device=device)
+        rc = L.pcs_mix_jacobian(int(bool(dew)), _lib.ptr(params), _lib.ptr(kij), _lib.ptr(temperature),
+                                _lib.ptr(rho4), n, _lib.ptr(jac), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_mix_jacobian")
+    return jac

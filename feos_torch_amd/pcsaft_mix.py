@@ -1,0 +1,119 @@
+"""``PcSaftMix`` — drop-in for the reference class of the same name
+(feos_torch/pcsaft_mix.py:12-479) backed by the gfx950 kernels.
+
+Same constructor ``PcSaftMix(parameters[N,2,8], kij[N,2])``, methods ``bubble_point`` /
+``dew_point(temperature, molefracs, pressure)`` returning ``(pressure [Pa], nans)`` — note the
+tuple order is the opposite of ``PcSaftPure`` in the reference too (:444, :468) — values only
+for converged rows, and the model is reduced (mutated) by every property call (:470-479).
+Gradients flow to ``parameters``, ``kij`` and ``temperature`` (the reference's final formula
+does not depend on the mole fractions or the initial pressure explicitly, so those receive
+zero gradient there; here they receive none).
+"""
+import torch
+
+from . import native
+
+
+class _BubbleDew(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dew, parameters, kij, temperature, molefracs, pressure):
+        out_device = parameters.device
+        dev = native._dev() if not parameters.is_cuda else parameters.device
+        par = native._prep(parameters, dev, (2, 8))
+        k = native._prep(kij, dev, (2,))
+        T = native._prep(temperature, dev)
+        z = native._prep(molefracs, dev)
+        p0 = native._prep(pressure, dev)
+        r = native.mix_bubble_dew(par, k, T, z, p0, dew)
+        nans = r["status"]
+        ok = ~nans
+        value = r["p"][ok]
+        needs = list(ctx.needs_input_grad[1:4])
+        if any(needs):
+            jac = native.mix_jacobian(par[ok], k[ok], T[ok], r["rho4"][ok], dew)
+            ctx.save_for_backward(jac, ok)
+        ctx.needs = needs
+        ctx.n = T.shape[0]
+        ctx.in_devices = (parameters.device, kij.device, temperature.device)
+        nans = nans.to(out_device)
+        ctx.mark_non_differentiable(nans)
+        return value.to(out_device), nans
+
+    @staticmethod
+    def backward(ctx, g_value, _g_nans):
+        jac, ok = ctx.saved_tensors
+        g = g_value.to(jac.device)
+        n = ctx.n
+        gp = gk = gt = None
+        if ctx.needs[0]:
+            gp = torch.zeros((n, 16), dtype=torch.float64, device=jac.device)
+            gp[ok] = g[:, None] * jac[:, 0:16]
+            gp = gp.view(n, 2, 8).to(ctx.in_devices[0])
+        if ctx.needs[1]:
+            gk = torch.zeros((n, 2), dtype=torch.float64, device=jac.device)
+            gk[ok] = g[:, None] * jac[:, 16:18]
+            gk = gk.to(ctx.in_devices[1])
+        if ctx.needs[2]:
+            gt = torch.zeros(n, dtype=torch.float64, device=jac.device)
+            gt[ok] = g * jac[:, 18]
+            gt = gt.to(ctx.in_devices[2])
+        return None, gp, gk, gt, None, None
+
+
+class PcSaftMix:
+    def __init__(self, parameters, kij=None):
+        """parameters: [N, 2, 8] float64 (component rows as for PcSaftPure); kij: [N, 2] with
+        kij[:,0] = k_ij and kij[:,1] = explicit cross-association energy eps_AiBj/k or 0
+        (feos_torch/pcsaft_mix.py:13-29; effectively mandatory in the reference, :141/:477)."""
+        if parameters.dim() != 3 or tuple(parameters.shape[1:]) != (2, 8):
+            raise ValueError("parameters must have shape [N, 2, 8] (binary mixtures)")
+        if kij is None:
+            kij = torch.zeros((parameters.shape[0], 2), dtype=parameters.dtype, device=parameters.device)
+        self._set(parameters, kij)
+
+    def _set(self, parameters, kij):
+        self._par = parameters
+        self.kij = kij
+        self.m = parameters[:, :, 0]
+        self.sigma = parameters[:, :, 1]
+        self.epsilon_k = parameters[:, :, 2]
+        self.mu2 = parameters[:, :, 3] ** 2 / (self.m * self.sigma**3 * self.epsilon_k) * 1e-19 * (1.0 / 1.380649e-23)
+        self.kappa_ab = parameters[:, :, 4]
+        self.epsilon_k_ab = parameters[:, :, 5]
+        self.na = parameters[:, :, 6]
+        self.nb = parameters[:, :, 7]
+
+    @property
+    def parameters(self):
+        return self._par.detach().cpu().numpy()
+
+    @property
+    def kij_np(self):
+        return self.kij.detach().cpu().numpy()
+
+    def helmholtz_energy_density(self, temperature, density):
+        """a(T, rho_1, rho_2) [A^-3], shape [N, 1] like the reference (:31-154).  Forward only."""
+        return self.derivatives(temperature, density)[0][:, None]
+
+    def derivatives(self, temperature, density):
+        """(a [N], p [N], mu [N,2], v [N,2]) (:395-420).  Forward only."""
+        a, p, mu, v = native.mix_derivatives(self._par, self.kij, temperature, density)
+        dev = self._par.device
+        return a.to(dev), p.to(dev), mu.to(dev), v.to(dev)
+
+    def bubble_point(self, temperature, liquid_molefracs, pressure):
+        """(p [Pa], nans) at T [K], liquid mole fraction of component 1, initial pressure [Pa] (:422-444)."""
+        value, nans = _BubbleDew.apply(False, self._par, self.kij, temperature, liquid_molefracs, pressure)
+        self.reduce(nans)
+        return value, nans
+
+    def dew_point(self, temperature, vapor_molefracs, pressure):
+        """(p [Pa], nans) at T [K], vapour mole fraction of component 1, initial pressure [Pa] (:446-468)."""
+        value, nans = _BubbleDew.apply(True, self._par, self.kij, temperature, vapor_molefracs, pressure)
+        self.reduce(nans)
+        return value, nans
+
+    def reduce(self, nans):
+        """Drop the rows flagged in ``nans`` (:470-479)."""
+        keep = ~nans.to(self._par.device)
+        self._set(self._par[keep], self.kij[keep.to(self.kij.device)])

@@ -99,6 +99,41 @@ int pcs_pure_derivatives(const double* params, const double* temp, const double*
 int pcs_pure_jacobian(int which, const double* params, const double* temp, const double* pressure,
                       const double* rho_vl, int64_t n, double* jac, void* stream);
 
+/*
+ * Binary-mixture bubble point (dew = 0: z = liquid mole fraction of component 1) or dew point
+ * (dew = 1: z = vapour mole fraction of component 1) at fixed temperature.
+ * Replaces PcSaft.bubble_point / PcSaft.dew_point(parameters[N,2,8], kij[N,2], temperature[N],
+ * molefracs[N], pressure[N]) -> (rho[n_ok,4], status[N])  (src/pcsaft.rs:43-79, :150-231) and
+ * the Python tails PcSaftMix.bubble_point / dew_point (feos_torch/pcsaft_mix.py:422-468).
+ *   params  [n,2,8] in    component rows as for the pure model
+ *   kij     [n,2]   in    kij[:,0] = k_ij, kij[:,1] = explicit eps_AiBj/k, 0 = combining rule
+ *                         (src/pcsaft.rs:163, pcsaft_mix.py:509-516)
+ *   temp, z, p_init [n] in    K, -, Pa (p_init = the caller's starting pressure, src/pcsaft.rs:174)
+ *   p_out   [n]     out   Pa   pcsaft_mix.py:443-444 / :467-468                 (optional)
+ *   rho4    [n,4]   out   A^-3 (rhoV_1, rhoV_2, rhoL_1, rhoL_2), src/pcsaft.rs:225-228 (optional)
+ *   status  [n]     out   uint8, 1 = failed
+ *   iters   [n]     out   int32 Newton iterations (optional)
+ */
+int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const double* temp, const double* z,
+                       const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status, int32_t* iters,
+                       void* stream);
+
+/*
+ * PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420) at given partial densities rho [n,2]:
+ * a [n], p [n] (reduced), residual chemical potentials mu [n,2], partial molar volumes v [n,2].
+ * Any output may be NULL.
+ */
+int pcs_mix_derivatives(const double* params, const double* kij, const double* temp, const double* rho, int64_t n,
+                        double* a, double* p, double* mu, double* v, void* stream);
+
+/*
+ * Gradient of the bubble (dew = 0) / dew (dew = 1) pressure [Pa] at the converged densities rho4
+ * (from pcs_mix_bubble_dew) — what torch reverse mode through feos_torch/pcsaft_mix.py:435-444 /
+ * :459-468 yields.  jac [n,19] = d p / d (params[0,0..7], params[1,0..7], kij[0], kij[1], T).
+ */
+int pcs_mix_jacobian(int dew, const double* params, const double* kij, const double* temp, const double* rho4,
+                     int64_t n, double* jac, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

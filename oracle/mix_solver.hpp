@@ -1,0 +1,222 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see dual.hpp header).
+//
+// Bubble- / dew-point iteration for binary mixtures.  In the reference this is feos'
+// PhaseEquilibrium::bubble_point / dew_point (src/pcsaft.rs:170-178, :203-211; src/gc_pcsaft.rs:
+// 124-133, :159-168) — third-party crate feos = "0.6" (Cargo.toml:18), absent from
+// /root/reference.  Restated from the published problem statement: at fixed T and fixed
+// composition z of the SPECIFIED phase (liquid for bubble, vapour for dew) find the total
+// density of that phase and the two partial densities of the INCIPIENT phase such that
+//     mu_i^spec = mu_i^inc (i = 1, 2),   p^spec = p^inc,
+// mu_i = ln rho_i + da/drho_i,  p = sum rho - a + sum rho_k da/drho_k   (all reduced).
+// Newton in the logarithms of the three unknowns; initialisation from ideal-gas / ideal-
+// solution estimates (bubble: liquid at the initial pressure, vapour partial densities from
+// the liquid fugacities; dew: Raoult's law with zero-pressure pure-liquid fugacities).
+// The result the reference returns is one further explicit Newton step
+// (feos_torch/pcsaft_mix.py:443, :467) whose density derivatives vanish at the solution, so it
+// depends on the Helmholtz model only.
+//
+// Model-agnostic: `Model` provides  template<class S> S a(const S& T, const S* rho) const
+// (reduced residual Helmholtz energy density) and  F packing(F T, const F* x)  =
+// zeta3 / rho_total at composition x.  Used for PcSaftMix and GcPcSaftMix.
+#pragma once
+#include "dual.hpp"
+
+namespace oracle {
+
+template <class F>
+struct PhaseEval {
+    F a, g[2], h[2][2];  // a, da/drho_i, d2a/drho_i drho_j
+    F rho[2];
+    F mu(int i) const { return log(rho[i]) + g[i]; }
+    F mu_res(int i) const { return g[i]; }
+    F p() const { return rho[0] + rho[1] - a + rho[0] * g[0] + rho[1] * g[1]; }
+    F dmu(int i, int j) const { return (i == j ? F(1) / rho[i] : F(0)) + h[i][j]; }
+    F dp(int j) const { return F(1) + rho[0] * h[0][j] + rho[1] * h[1][j]; }
+};
+
+// full gradient + Hessian from two hyper-dual passes (eps2 along rho_1, then along rho_2)
+template <class F, class Model>
+PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
+    typedef HyperDual<F, 2> H;
+    PhaseEval<F> e;
+    e.rho[0] = rho[0];
+    e.rho[1] = rho[1];
+    for (int k = 0; k < 2; k++) {
+        H r[2];
+        for (int i = 0; i < 2; i++) {
+            r[i].re = rho[i];
+            r[i].eps1[i] = F(1);
+            if (i == k) r[i].eps2 = F(1);
+        }
+        H Th;
+        Th.re = T;
+        H A = model.template a<H>(Th, r);
+        e.a = A.re;
+        e.g[0] = A.eps1[0];
+        e.g[1] = A.eps1[1];
+        e.h[0][k] = A.eps1eps2[0];
+        e.h[1][k] = A.eps1eps2[1];
+    }
+    return e;
+}
+
+// dense-side Newton for p(rho_total) = p_spec at fixed composition x (liquid-like root)
+template <class F, class Model>
+bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out) {
+    F rho = F(0.5) / model.packing(T, x);
+    F err_prev = F(1);
+    for (int it = 0; it < 200; it++) {
+        F r[2] = {x[0] * rho, x[1] * rho};
+        PhaseEval<F> e = eval_phase<F>(model, T, r);
+        F p = e.p(), dp = x[0] * e.dp(0) + x[1] * e.dp(1);
+        if (it == 0 && !(p > p_spec)) { rho = F(0.62) / model.packing(T, x); continue; }
+        if (!(dp > 0) || !(p == p)) return false;
+        F step = (p - p_spec) / dp;
+        F rho_new = rho - step;
+        if (!(rho_new > 0)) return false;
+        F err = (step < 0 ? -step : step) / rho;
+        bool done = err <= F(1e-10) || (it >= 3 && err < F(1e-7) && err >= F(0.25) * err_prev);
+        err_prev = err;
+        rho = rho_new;
+        if (done) { rho_out = rho; return true; }
+    }
+    return false;
+}
+
+template <class F>
+bool solve3(F J[3][3], const F* b, F* x) {  // Gaussian elimination with partial pivoting
+    F A[3][4];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) A[i][j] = J[i][j]; A[i][3] = b[i]; }
+    for (int c = 0; c < 3; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 3; r++) if (fabsl((long double)A[r][c]) > fabsl((long double)A[piv][c])) piv = r;
+        if (A[piv][c] == 0) return false;
+        for (int j = 0; j < 4; j++) { F t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+        for (int r = c + 1; r < 3; r++) {
+            F f = A[r][c] / A[c][c];
+            for (int j = c; j < 4; j++) A[r][j] -= f * A[c][j];
+        }
+    }
+    for (int i = 2; i >= 0; i--) {
+        F s = A[i][3];
+        for (int j = i + 1; j < 3; j++) s -= A[i][j] * x[j];
+        x[i] = s / A[i][i];
+    }
+    return true;
+}
+
+struct MixSolveInfo { int iters; };
+
+// z = mole fraction of component 1 in the specified phase; p_init [reduced] = caller's initial
+// pressure (src/pcsaft.rs:174 passes it to feos as Some(p)).  Outputs partial densities.
+template <class F, class Model>
+bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, F* rho_inc, MixSolveInfo& info, F tol) {
+    F z[2] = {z1, F(1) - z1};
+    F rs, ri[2];  // total density of the specified phase, partial densities of the incipient one
+    info.iters = 0;
+    if (!dew) {
+        // liquid at the initial pressure (fallback: zero pressure), ideal vapour at its fugacities
+        if (!liquid_root<F>(model, T, z, p_init, rs) && !liquid_root<F>(model, T, z, F(0), rs)) return false;
+        F r[2] = {z[0] * rs, z[1] * rs};
+        PhaseEval<F> e = eval_phase<F>(model, T, r);
+        for (int i = 0; i < 2; i++) ri[i] = r[i] * exp(e.g[i]);
+    } else {
+        // Raoult: zero-pressure pure-liquid fugacities f_i, p = 1/sum(y_i/f_i), x_i = y_i p/f_i
+        F f[2];
+        bool ok = true;
+        for (int i = 0; i < 2; i++) {
+            F xi[2] = {i == 0 ? F(1) : F(0), i == 1 ? F(1) : F(0)};
+            F rho0;
+            if (!liquid_root<F>(model, T, xi, F(0), rho0)) { ok = false; break; }
+            F r[2] = {xi[0] * rho0, xi[1] * rho0};
+            PhaseEval<F> e = eval_phase<F>(model, T, r);
+            f[i] = rho0 * exp(e.g[i]);
+        }
+        F x[2], p0;
+        if (ok) {
+            p0 = F(1) / (z[0] / f[0] + z[1] / f[1]);
+            x[0] = z[0] * p0 / f[0];
+            x[1] = z[1] * p0 / f[1];
+        } else {
+            p0 = p_init;
+            x[0] = z[0];
+            x[1] = z[1];
+        }
+        // successive substitution with an ideal vapour: the liquid sits at (nearly) zero pressure,
+        // f_i = rho^L_i exp(da/drho_i) are its fugacities, y_i p = f_i fixes the next composition:
+        //   x_i <- (y_i x_i / f_i) / sum_j (y_j x_j / f_j),   p = 1 / sum_j (y_j x_j / f_j)
+        F rl = 0;
+        bool have = false;
+        for (int ss = 0; ss < 200; ss++) {
+            if (!liquid_root<F>(model, T, x, F(0), rl)) {
+                if (!liquid_root<F>(model, T, x, p0, rl)) return false;
+            }
+            have = true;
+            F r[2] = {x[0] * rl, x[1] * rl};
+            PhaseEval<F> e = eval_phase<F>(model, T, r);
+            F w[2];
+            for (int i = 0; i < 2; i++) w[i] = z[i] * x[i] / (r[i] * exp(e.g[i]));
+            F sum = w[0] + w[1];
+            F xn[2] = {w[0] / sum, w[1] / sum};
+            F dx = xn[0] - x[0];
+            if (dx < 0) dx = -dx;
+            // damp when a component would change by more than a factor 5 in one sweep
+            for (int i = 0; i < 2; i++) {
+                if (xn[i] > F(5) * x[i]) xn[i] = F(5) * x[i];
+                if (xn[i] < F(0.2) * x[i]) xn[i] = F(0.2) * x[i];
+            }
+            F s2 = xn[0] + xn[1];
+            x[0] = xn[0] / s2;
+            x[1] = xn[1] / s2;
+            p0 = F(1) / sum;
+            if (dx < F(1e-7)) break;
+        }
+        if (!have) return false;
+        if (!liquid_root<F>(model, T, x, p0, rl) && !liquid_root<F>(model, T, x, F(0), rl)) return false;
+        ri[0] = x[0] * rl;
+        ri[1] = x[1] * rl;
+        rs = p0;  // ideal vapour
+    }
+    // Newton in (ln rho_spec, ln rho_inc_1, ln rho_inc_2)
+    F err_prev = F(1);
+    for (int it = 0; it < 200; it++) {
+        F r_s[2] = {z[0] * rs, z[1] * rs};
+        PhaseEval<F> s = eval_phase<F>(model, T, r_s);
+        PhaseEval<F> n = eval_phase<F>(model, T, ri);
+        F Fv[3] = {s.mu(0) - n.mu(0), s.mu(1) - n.mu(1), s.p() - n.p()};
+        F J[3][3];
+        for (int i = 0; i < 2; i++) {
+            J[i][0] = rs * (z[0] * s.dmu(i, 0) + z[1] * s.dmu(i, 1));
+            J[i][1] = -ri[0] * n.dmu(i, 0);
+            J[i][2] = -ri[1] * n.dmu(i, 1);
+        }
+        J[2][0] = rs * (z[0] * s.dp(0) + z[1] * s.dp(1));
+        J[2][1] = -ri[0] * n.dp(0);
+        J[2][2] = -ri[1] * n.dp(1);
+        F rhs[3] = {-Fv[0], -Fv[1], -Fv[2]}, du[3];
+        if (!solve3<F>(J, rhs, du)) return false;
+        F mx = 0;
+        for (int k = 0; k < 3; k++) { F a = du[k] < 0 ? -du[k] : du[k]; if (a > mx) mx = a; }
+        if (!(mx == mx)) return false;
+        F scale = mx > F(1) ? F(1) / mx : F(1);  // at most a factor e per iteration
+        rs = rs * exp(scale * du[0]);
+        ri[0] = ri[0] * exp(scale * du[1]);
+        ri[1] = ri[1] * exp(scale * du[2]);
+        info.iters = it + 1;
+        bool stagnated = it >= 3 && mx < F(1e-7) && mx >= F(0.25) * err_prev;
+        err_prev = mx;
+        if (mx <= tol || stagnated) {
+            F dens_s = rs, dens_i = ri[0] + ri[1];
+            F lo = dew ? dens_s : dens_i, hi = dew ? dens_i : dens_s;  // vapour, liquid
+            if (!(lo < hi * (F(1) - F(1e-6)))) return false;           // trivial solution
+            rho_spec[0] = z[0] * rs;
+            rho_spec[1] = z[1] * rs;
+            rho_inc[0] = ri[0];
+            rho_inc[1] = ri[1];
+            return true;
+        }
+    }
+    return false;
+}
+
+}  // namespace oracle

@@ -7,7 +7,8 @@
 #include <cstring>
 #include <omp.h>
 #include "pcsaft_pure.hpp"
-// #include "pcsaft_mix.hpp"  (added with the mixture oracle)
+#include "pcsaft_mix.hpp"
+#include "mix_solver.hpp"
 
 using namespace oracle;
 
@@ -253,6 +254,139 @@ int orc_dual3_selftest() {
     k++; if (!eq(exp(x), std::exp(4.0), std::exp(4.0), std::exp(4.0))) return k;
     k++; if (!eq(sqrt(x), 2, 0.25, -1.0 / 32)) return k;
     return 0;
+}
+
+// ======================================================================================
+// binary mixtures (feos_torch/pcsaft_mix.py)
+// ======================================================================================
+}  // extern "C"
+
+namespace {
+
+template <class S, class F>
+S lift_to(const F& x) { S s(0.0); s.re = x; return s; }
+template <> double lift_to<double, double>(const double& x) { return x; }
+template <> long double lift_to<long double, long double>(const long double& x) { return x; }
+
+template <class S, class F>
+MixParams<S> lift_mix(const MixParams<F>& q) {
+    MixParams<S> r;
+    for (int i = 0; i < 2; i++) {
+        r.m[i] = lift_to<S, F>(q.m[i]); r.sigma[i] = lift_to<S, F>(q.sigma[i]); r.epsilon_k[i] = lift_to<S, F>(q.epsilon_k[i]);
+        r.mu2[i] = lift_to<S, F>(q.mu2[i]); r.kappa_ab[i] = lift_to<S, F>(q.kappa_ab[i]);
+        r.epsilon_k_ab[i] = lift_to<S, F>(q.epsilon_k_ab[i]); r.na[i] = lift_to<S, F>(q.na[i]); r.nb[i] = lift_to<S, F>(q.nb[i]);
+    }
+    r.kij = lift_to<S, F>(q.kij);
+    r.eps_aibj = lift_to<S, F>(q.eps_aibj);
+    r.robust = q.robust;
+    return r;
+}
+
+// adapter: PcSaftMix as a `Model` for mix_solver.hpp
+template <class F>
+struct MixModel {
+    MixParams<F> q;
+    template <class S> S a(const S& T, const S* rho) const {
+        MixParams<S> qs = lift_mix<S, F>(q);
+        return helmholtz_energy_density_mix<S>(qs, T, rho);
+    }
+    F packing(F T, const F* x) const {
+        F s = 0;
+        for (int i = 0; i < 2; i++) {
+            F d = q.sigma[i] * (F(1) - F(0.12) * oracle::exp(F(-3) * q.epsilon_k[i] / T));
+            s += x[i] * q.m[i] * d * d * d;
+        }
+        return F(PI) / F(6) * s;
+    }
+};
+
+template <class F>
+MixParams<F> load_mix(const double* par16, const double* kij2) {
+    F p[16];
+    for (int k = 0; k < 16; k++) p[k] = F(par16[k]);
+    return make_mix_params<F>(p, F(kij2[0]), F(kij2[1]));
+}
+
+template <class F>
+void mix_bd_row(const double* par16, const double* kij2, double T, double z, double p_pa, bool dew, F tol,
+                double* rho4, double* p_out, uint8_t* status) {
+    MixModel<F> model{load_mix<F>(par16, kij2)};
+    model.q.robust = true;
+    F rs[2], ri[2];
+    MixSolveInfo info;
+    F p_red = F(p_pa) / F(T) * F(1.0 / P_UNIT);
+    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol);
+    *status = ok ? 0 : 1;
+    // reference layout (src/pcsaft.rs:225-228): [rhoV_1, rhoV_2, rhoL_1, rhoL_2]
+    const F* v = dew ? rs : ri;
+    const F* l = dew ? ri : rs;
+    if (rho4) {
+        rho4[0] = ok ? double(v[0]) : 0.0; rho4[1] = ok ? double(v[1]) : 0.0;
+        rho4[2] = ok ? double(l[0]) : 0.0; rho4[3] = ok ? double(l[1]) : 0.0;
+    }
+    if (p_out) *p_out = ok ? double(bubble_dew_formula<F>(model.q, F(T), rs, ri)) : 0.0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420)
+void orc_mix_derivatives(const double* params, const double* kij, const double* T, const double* rho, int64_t n,
+                         int robust, double* a, double* p, double* mu, double* v) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        MixParams<double> q = load_mix<double>(params + 16 * i, kij + 2 * i);
+        q.robust = robust != 0;
+        derivatives_mix<double>(q, T[i], rho + 2 * i, a[i], p[i], mu + 2 * i, v + 2 * i);
+    }
+}
+
+// plain helmholtz_energy_density (:31-154)
+void orc_mix_helmholtz(const double* params, const double* kij, const double* T, const double* rho, int64_t n,
+                       double* a) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        MixParams<double> q = load_mix<double>(params + 16 * i, kij + 2 * i);
+        a[i] = helmholtz_energy_density_mix<double>(q, T[i], rho + 2 * i);
+    }
+}
+
+// converged partial densities [n,4] = (rhoV_1, rhoV_2, rhoL_1, rhoL_2) + status, and the property
+// (bubble / dew pressure, Pa) from the reference's final formula.  Either output may be NULL.
+void orc_mix_bubble_dew(const double* params, const double* kij, const double* T, const double* z,
+                        const double* p_init_pa, int64_t n, int dew, int prec, double* rho4, double* p_out,
+                        uint8_t* status) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n; i++) {
+        if (prec == 1)
+            mix_bd_row<long double>(params + 16 * i, kij + 2 * i, T[i], z[i], p_init_pa[i], dew != 0, 1e-17L,
+                                    rho4 ? rho4 + 4 * i : nullptr, p_out ? p_out + i : nullptr, status + i);
+        else
+            mix_bd_row<double>(params + 16 * i, kij + 2 * i, T[i], z[i], p_init_pa[i], dew != 0, 1e-13,
+                               rho4 ? rho4 + 4 * i : nullptr, p_out ? p_out + i : nullptr, status + i);
+    }
+}
+
+// Value and gradient of the bubble / dew pressure formula (pcsaft_mix.py:435-444 / :459-468) at
+// FIXED densities rho4 = (rhoV_1, rhoV_2, rhoL_1, rhoL_2): grad[n,19] = d/d(16 parameters
+// [comp0 x 8, comp1 x 8], kij[0], kij[1], T) — what torch reverse mode yields in the reference.
+void orc_mix_bubble_dew_grad(const double* params, const double* kij, const double* T, const double* rho4,
+                             int64_t n, int dew, double* value, double* grad) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        typedef DualN<double, 19> G;
+        G p[16];
+        for (int k = 0; k < 16; k++) p[k] = G::var(params[16 * i + k], k);
+        MixParams<G> q = make_mix_params<G>(p, G::var(kij[2 * i], 16), G::var(kij[2 * i + 1], 17));
+        // `var` on eps_aibj == 0 keeps re == 0, so the mean combining rule is still selected
+        q.robust = true;
+        G Tg = G::var(T[i], 18);
+        G rv[2] = {G(rho4[4 * i]), G(rho4[4 * i + 1])}, rl[2] = {G(rho4[4 * i + 2]), G(rho4[4 * i + 3])};
+        G r = dew ? bubble_dew_formula<G>(q, Tg, rv, rl) : bubble_dew_formula<G>(q, Tg, rl, rv);
+        value[i] = r.re;
+        for (int k = 0; k < 19; k++) grad[19 * i + k] = r.eps[k];
+    }
 }
 
 }  // extern "C"

@@ -56,6 +56,10 @@ def lib():
         L.orc_pure_liquid_density_root.argtypes = [_f64p, _f64p, _f64p, _i64, _int, _f64p, _u8p]
         L.orc_pure_equilibrium_liquid_density.argtypes = [_f64p, _f64p, _i64, _int, _f64p, _u8p]
         L.orc_pure_property_grad.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _f64p, _f64p]
+        L.orc_mix_derivatives.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p, _f64p, _f64p]
+        L.orc_mix_helmholtz.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p]
+        L.orc_mix_bubble_dew.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _u8p]
+        L.orc_mix_bubble_dew_grad.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p]
         _lib = L
     return _lib
 
@@ -157,4 +161,49 @@ def pure_property_grad(which, params, T, p_pa, rho_v, rho_l):
     val, grad = np.empty(n), np.empty((n, 10))
     lib().orc_pure_property_grad({"vapor_pressure": 0, "liquid_density": 1, "equilibrium_liquid_density": 2}[which],
                                  params, T, p_pa, rho_v, rho_l, n, val, grad)
+    return val, grad
+
+
+# ------------------------------------------------------------------------------------------
+# binary mixtures
+# ------------------------------------------------------------------------------------------
+def mix_derivatives(params, kij, T, rho, robust=False):
+    """PcSaftMix.derivatives: a[n], p[n], mu[n,2], v[n,2] (reduced).  robust=False runs the
+    association sub-iterations literally as the reference does; True uses the safeguarded form."""
+    params, kij, T, rho = _c(params), _c(kij), _c(T), _c(rho)
+    n = T.shape[0]
+    a, p, mu, v = np.empty(n), np.empty(n), np.empty((n, 2)), np.empty((n, 2))
+    lib().orc_mix_derivatives(params, kij, T, rho, n, int(bool(robust)), a, p, mu, v)
+    return a, p, mu, v
+
+
+def mix_helmholtz(params, kij, T, rho):
+    params, kij, T, rho = _c(params), _c(kij), _c(T), _c(rho)
+    a = np.empty(T.shape[0])
+    lib().orc_mix_helmholtz(params, kij, T, rho, T.shape[0], a)
+    return a
+
+
+def mix_bubble_dew(params, kij, T, z, p_init, dew, prec=1):
+    """-> p [Pa] (dense), rho4 [n,4] = (rhoV_1, rhoV_2, rhoL_1, rhoL_2) A^-3 (dense), status"""
+    params, kij, T, z, p_init = _c(params), _c(kij), _c(T), _c(z), _c(p_init)
+    n = T.shape[0]
+    rho4, p = np.empty((n, 4)), np.empty(n)
+    st = np.empty(n, dtype=np.uint8)
+    lib().orc_mix_bubble_dew(params, kij, T, z, p_init, n, int(bool(dew)), prec, rho4, p, st)
+    return p, rho4, st.astype(bool)
+
+
+def mix_bubble_dew_root(params, kij, T, z, p_init, dew, prec=1):
+    """-> rho4 (dense), status — the role of src/pcsaft.rs:150-231"""
+    _, rho4, st = mix_bubble_dew(params, kij, T, z, p_init, dew, prec)
+    return rho4, st
+
+
+def mix_bubble_dew_grad(params, kij, T, rho4, dew):
+    """value[n], grad[n,19] = d/d(16 params, kij0, kij1, T) at fixed densities."""
+    params, kij, T, rho4 = _c(params), _c(kij), _c(T), _c(rho4)
+    n = T.shape[0]
+    val, grad = np.empty(n), np.empty((n, 19))
+    lib().orc_mix_bubble_dew_grad(params, kij, T, rho4, n, int(bool(dew)), val, grad)
     return val, grad

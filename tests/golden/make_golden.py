@@ -180,6 +180,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["pure", "mix", "gc"]
     if "pure" in which:
         make_pure()
+    sys.path.insert(0, HERE)
     if "mix" in which:
         from make_golden_mix import make_mix
         make_mix(PcSaftMix, dump, tl)

@@ -1,0 +1,82 @@
+"""Mixture / gc parts of make_golden.py (run through that script; see its docstring)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+f64 = torch.float64
+
+# tests/test_pcsaft_mix.py:17-39
+MIX_TEST_PARAMS = [
+    [[1.5, 3.2, 150, 0, 0, 0, 0, 0], [2.5, 3.5, 250, 0, 0, 0, 0, 0]],
+    [[1.5, 3.2, 150, 2.5, 0, 0, 0, 0], [2.5, 3.5, 250, 0, 0, 0, 0, 0]],
+    [[1.5, 3.2, 150, 0, 0, 0, 0, 0], [2.5, 3.5, 250, 2, 0, 0, 0, 0]],
+    [[1.5, 3.2, 150, 2.5, 0, 0, 0, 0], [2.5, 3.5, 250, 2, 0, 0, 0, 0]],
+    [[1.5, 3.2, 150, 0, 0.03, 2500, 2, 1], [2.5, 3.5, 250, 0, 0, 0, 0, 0]],
+    [[1.5, 3.2, 150, 0, 0, 0, 0, 0], [2.5, 3.5, 250, 0, 0.025, 1500, 1, 2]],
+    [[1.5, 3.2, 150, 0, 0.03, 2500, 1, 1], [2.5, 3.5, 250, 0, 0.025, 1500, 1, 1]],
+    [[1.5, 3.2, 150, 2.5, 0.03, 2500, 1, 1], [2.5, 3.5, 250, 2, 0.025, 1500, 1, 1]],
+    [[1.5, 3.2, 150, 0, 0.03, 2500, 1, 1], [2.5, 3.5, 250, 0, 0.025, 1500, 0, 1]],
+    [[1.5, 3.2, 150, 0, 0.03, -500, 0, 2], [2.5, 3.5, 250, 0, 0.025, 1500, 1, 1]],
+    [[1.5, 3.2, 150, 0, 0, 0, 0, 0], [2.5, 3.5, 250, 0, 0.025, 1500, 0, 1]],
+    [[1.5, 3.2, 150, 0, 0.03, 2500, 2, 2], [2.5, 3.5, 250, 0, 0.025, 1500, 1, 1]],
+    [[1.5, 3.2, 150, 0, 0.03, 2500, 2, 2], [2.5, 3.5, 250, 0, 0.025, 1500, 1, 1]],
+    [[1.5, 3.2, 150, 0, 0.03, 2500, 1, 2], [2.5, 3.5, 250, 0, 0.025, 1500, 2, 1]],
+]
+
+
+def _bubble_dew(PcSaftMix, tl, params, kij, T, z, p, dew):
+    x = torch.tensor(params, dtype=f64, requires_grad=True)
+    k = torch.tensor(kij, dtype=f64, requires_grad=True)
+    Tt = torch.tensor(T, dtype=f64, requires_grad=True)
+    zt = torch.tensor(z, dtype=f64)
+    pt = torch.tensor(p, dtype=f64)
+    eos = PcSaftMix(x, k)
+    val, nans = (eos.dew_point if dew else eos.bubble_point)(Tt, zt, pt)
+    val.sum().backward()
+    return {"nans": tl(nans), "value": tl(val), "grad_params": tl(x.grad), "grad_kij": tl(k.grad), "grad_T": tl(Tt.grad)}
+
+
+def make_mix(PcSaftMix, dump, tl):
+    g = {}
+    n = len(MIX_TEST_PARAMS)
+    kij = [[-0.05, 0.0] for _ in range(n)]
+    kij[12][1] = 3000.0
+    T = [300.0] * n
+    rho = [[0.001, 0.002]] * n
+    eos = PcSaftMix(torch.tensor(MIX_TEST_PARAMS, dtype=f64), torch.tensor(kij, dtype=f64))
+    a, p, mu, v = eos.derivatives(torch.tensor(T, dtype=f64), torch.tensor(rho, dtype=f64))
+    g["test_inputs"] = {"params": MIX_TEST_PARAMS, "kij": kij, "T": T, "rho": rho, "a": tl(a), "p": tl(p), "mu": tl(mu), "v": tl(v)}
+
+    # tests/test_pcsaft_mix.py:127-192 (bubble) and :195-251 (dew): two rows differing by h in k_ij
+    h = 1e-8
+    pb = [[[1, 3.5, 150, 0, 0.02, 1500, 1, 1], [1, 3.5, 200, 0, 0.03, 2500, 1, 1]]] * 2
+    kb = [[-0.15, 1000.0], [-0.15 + h, 1000.0]]
+    g["test_bubble"] = {"params": pb, "kij": kb, "T": [150.0] * 2, "z": [0.5] * 2, "p_init": [1e5] * 2, "h": h}
+    g["test_bubble"]["result"] = _bubble_dew(PcSaftMix, tl, pb, kb, [150.0] * 2, [0.5] * 2, [1e5] * 2, False)
+    pd = [[[1, 3.5, 150, 0, 0, 0, 0, 0], [1, 3.5, 200, 0, 0, 0, 0, 0]]] * 2
+    kd = [[-0.15, 0.0], [-0.15 + h, 0.0]]
+    g["test_dew"] = {"params": pd, "kij": kd, "T": [150.0] * 2, "z": [0.5] * 2, "p_init": [1e5] * 2, "h": h}
+    g["test_dew"]["result"] = _bubble_dew(PcSaftMix, tl, pd, kd, [150.0] * 2, [0.5] * 2, [1e5] * 2, True)
+
+    # seeded random rows of the config-4 distribution
+    from feos_torch_amd.synthetic import mix_batch
+    P, K, TT, X, PI = mix_batch(60, seed=17)
+    rng = np.random.default_rng(19)
+    eta = np.where(rng.random(60) < 0.5, rng.uniform(0.2, 0.42, 60), 10.0 ** rng.uniform(-7, -2, 60))
+    d = P[:, :, 1] * (1 - 0.12 * np.exp(-3 * P[:, :, 2] / TT[:, None]))
+    xx = np.stack([X, 1 - X], axis=1)
+    rho_tot = eta / (np.pi / 6 * (xx * P[:, :, 0] * d**3).sum(axis=1))
+    rho = xx * rho_tot[:, None]
+    eos = PcSaftMix(torch.tensor(P, dtype=f64), torch.tensor(K, dtype=f64))
+    a, p, mu, v = eos.derivatives(torch.tensor(TT, dtype=f64), torch.tensor(rho, dtype=f64))
+    g["random"] = {"params": P.tolist(), "kij": K.tolist(), "T": TT.tolist(), "z": X.tolist(), "p_init": PI.tolist(),
+                   "rho": rho.tolist(), "a": tl(a), "p": tl(p), "mu": tl(mu), "v": tl(v)}
+    g["random"]["bubble"] = _bubble_dew(PcSaftMix, tl, P.tolist(), K.tolist(), TT.tolist(), X.tolist(), PI.tolist(), False)
+    g["random"]["dew"] = _bubble_dew(PcSaftMix, tl, P.tolist(), K.tolist(), TT.tolist(), X.tolist(), PI.tolist(), True)
+    dump("mix.json", g)
+
+
+def make_gc(GcPcSaftMix, dump, tl):
+    raise NotImplementedError("gc fixtures are generated once the gc oracle exists")

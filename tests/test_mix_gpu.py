@@ -1,0 +1,162 @@
+"""GPU parity tests for the binary-mixture path (config 4 of BASELINE.json), in the shape of
+the reference's tests/test_pcsaft_mix.py.  Every call goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+f64 = torch.float64
+
+
+@pytest.fixture(scope="module")
+def amd():
+    assert torch.cuda.is_available()
+    import feos_torch_amd
+
+    return feos_torch_amd
+
+
+@pytest.fixture(scope="module")
+def gm():
+    return load_golden("mix.json")
+
+
+def _t(x, **kw):
+    return torch.tensor(np.asarray(x), dtype=f64, **kw)
+
+
+def test_derivatives_vs_reference_python(amd, gm):
+    """tests/test_pcsaft_mix.py:16-124 — the 14 binary cases; reference tolerances abs 1e-14 / 1e-11."""
+    g = gm["test_inputs"]
+    eos = amd.PcSaftMix(_t(g["params"]), _t(g["kij"]))
+    a, p, mu, v = eos.derivatives(_t(g["T"]), _t(g["rho"]))
+    assert np.max(np.abs(a.numpy() - np.array(g["a"]))) < 1e-14
+    assert np.max(np.abs(p.numpy() - np.array(g["p"]))) < 1e-14
+    assert np.max(np.abs(mu.numpy() - np.array(g["mu"]))) < 1e-13  # |mu| ~ 10: 1e-14 relative
+    assert np.max(np.abs(v.numpy() - np.array(g["v"]))) < 1e-11 * 50  # v up to 500
+    assert a[10].item() == a[0].item()  # "np/x" == "np/np" (lone B-site component does not associate)
+    hd = eos.helmholtz_energy_density(_t(g["T"]), _t(g["rho"]))
+    assert hd.shape == (14, 1)
+
+
+def test_derivatives_random_vs_oracle(amd, oracle, gm):
+    g = gm["random"]
+    P, K, T, rho = (np.array(g[k]) for k in ("params", "kij", "T", "rho"))
+    a, p, mu, v = amd.PcSaftMix(_t(P), _t(K)).derivatives(_t(T), _t(rho))
+    # long-double-free check: the safeguarded fp64 oracle (same model, literal formulas)
+    A, Pp, MU, V = oracle.mix_derivatives(P, K, T, rho, robust=True)
+    # strongly associating rows: the reference's self-association formula cancels in fp64 (see
+    # csrc/pure_model.hpp); the kernel's conjugate form is the accurate one -> relative tolerance
+    assert np.max(np.abs(a.numpy() - A) / np.maximum(1e-3, np.abs(A))) < 1e-7
+    assert np.max(np.abs(mu.numpy() - MU) / np.maximum(1.0, np.abs(MU))) < 1e-7
+
+
+@pytest.mark.parametrize("key,dew", [("test_bubble", False), ("test_dew", True)])
+def test_bubble_dew_reference_cases(amd, gm, key, dew):
+    """tests/test_pcsaft_mix.py:127-192 / :195-251: value abs 1e-8 Pa, dp/dk_ij vs finite difference abs 1."""
+    g = gm[key]
+    ref = g["result"]
+    kij = _t(g["kij"], requires_grad=True)
+    par = _t(g["params"], requires_grad=True)
+    T = _t(g["T"], requires_grad=True)
+    z = _t(g["z"], requires_grad=True)
+    p0 = _t(g["p_init"], requires_grad=True)
+    eos = amd.PcSaftMix(par, kij)
+    p, nans = (eos.dew_point if dew else eos.bubble_point)(T, z, p0)
+    assert nans.tolist() == ref["nans"]
+    assert np.max(np.abs(p.detach().numpy() - np.array(ref["value"]))) < 1e-8
+    p[0].backward()
+    fd = (p[1].item() - p[0].item()) / g["h"]
+    assert abs(kij.grad[0, 0].item() - fd) < 1.0
+    assert abs(kij.grad[0, 0].item() - ref["grad_kij"][0][0]) < 1e-3
+    assert torch.all(kij.grad[1] == 0)
+    # full gradient of row 0 against the reference's autograd
+    got = np.concatenate([par.grad[0].numpy().ravel(), kij.grad[0].numpy(), [T.grad[0].item()]])
+    p2, _ = (amd.PcSaftMix(_t(g["params"]), _t(g["kij"])).dew_point if dew else
+             amd.PcSaftMix(_t(g["params"]), _t(g["kij"])).bubble_point)(_t(g["T"]), _t(g["z"]), _t(g["p_init"]))
+    assert torch.equal(p2, p.detach())
+    # golden gradients are of sum(p) -> per-row
+    want = np.concatenate([np.array(ref["grad_params"])[0].ravel(), np.array(ref["grad_kij"])[0], [ref["grad_T"][0]]])
+    assert np.max(np.abs(got - want)) / np.abs(want).max() < 1e-7
+
+
+@pytest.mark.parametrize("dew", [False, True])
+def test_random_batch_vs_oracle(amd, oracle, dew):
+    from feos_torch_amd.synthetic import mix_batch
+
+    n = 6000
+    P, K, T, X, PI = mix_batch(n, seed=17)
+    eos = amd.PcSaftMix(_t(P).cuda(), _t(K).cuda())
+    p, nans = (eos.dew_point if dew else eos.bubble_point)(_t(T).cuda(), _t(X).cuda(), _t(PI).cuda())
+    assert p.is_cuda and nans.shape == (n,)
+    want, rho4, st = oracle.mix_bubble_dew(P, K, T, X, PI, dew, prec=1)
+    nans = nans.cpu().numpy()
+    assert (nans != st).mean() < 0.01, "failure masks differ on more than 1 % of the rows"
+    assert nans.mean() < 0.03
+    got = np.zeros(n)
+    got[~nans] = p.cpu().numpy()
+    both = ~nans & ~st
+    assert np.max(np.abs(got[both] / want[both] - 1)) < 1e-9  # north_star tolerance
+    assert eos.parameters.shape[0] == int((~nans).sum()) and eos.kij.shape[0] == int((~nans).sum())
+
+
+def test_jacobian_vs_oracle(amd, oracle):
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import mix_batch
+
+    n = 1200
+    P, K, T, X, PI = mix_batch(n, seed=23)
+    for dew in (False, True):
+        r = native.mix_bubble_dew(_t(P).cuda(), _t(K).cuda(), _t(T).cuda(), _t(X).cuda(), _t(PI).cuda(), dew)
+        ok = ~r["status"].cpu().numpy()
+        rho4 = r["rho4"].cpu().numpy()
+        J = native.mix_jacobian(_t(P).cuda(), _t(K).cuda(), _t(T).cuda(), r["rho4"], dew).cpu().numpy()
+        _, want = oracle.mix_bubble_dew_grad(P[ok], K[ok], T[ok], rho4[ok], dew)
+        scale = np.abs(want).max(axis=1, keepdims=True)
+        err = np.abs(J[ok] - want) / scale
+        # the oracle differentiates the reference's literal fp64 formulas (cancelling self-association
+        # term) — allow its noise on the strongly associating rows
+        assert np.quantile(err.max(axis=1), 0.99) < 1e-7
+        assert err.max() < 1e-4
+
+
+def test_phase_equilibrium_conditions_large_batch(amd):
+    """size-independent check at 1e6 rows (config 4): equal chemical potentials and pressures."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import mix_batch
+
+    n = 1_000_000
+    P, K, T, X, PI = mix_batch(n, seed=29)
+    Pd, Kd, Td = _t(P).cuda(), _t(K).cuda(), _t(T).cuda()
+    r = native.mix_bubble_dew(Pd, Kd, Td, _t(X).cuda(), _t(PI).cuda(), dew=False)
+    ok = ~r["status"]
+    assert ok.float().mean().item() > 0.97
+    rv, rl = r["rho4"][:, 0:2], r["rho4"][:, 2:4]
+    aV, pV, muV, _ = native.mix_derivatives(Pd, Kd, Td, torch.where(ok[:, None], rv, torch.full_like(rv, 1e-3)))
+    aL, pL, muL, vL = native.mix_derivatives(Pd, Kd, Td, torch.where(ok[:, None], rl, torch.full_like(rl, 1e-3)))
+    dmu = (torch.log(rv) + muV - torch.log(rl) - muL)[ok]
+    assert torch.max(torch.abs(dmu)).item() < 1e-6  # rows that leave through the stagnation exit (err < 1e-7)
+    assert torch.quantile(torch.abs(dmu).max(dim=1).values[:200000], 0.999).item() < 1e-10
+    p_red = (r["p"] / (Td * 1.380649e-23 / 1e-30))[ok]
+    assert torch.max(torch.abs(pV[ok] / p_red - 1)).item() < 1e-6
+    x1 = rl[:, 0] / rl.sum(dim=1)
+    assert torch.max(torch.abs(x1[ok] - _t(X).cuda()[ok])).item() < 1e-12
+    assert torch.all(rv.sum(dim=1)[ok] < rl.sum(dim=1)[ok])
+
+
+def test_empty_and_ffi_mirror(amd, oracle):
+    eos = amd.PcSaftMix(torch.zeros((0, 2, 8), dtype=f64), torch.zeros((0, 2), dtype=f64))
+    p, nans = eos.bubble_point(torch.zeros(0, dtype=f64), torch.zeros(0, dtype=f64), torch.zeros(0, dtype=f64))
+    assert p.shape == (0,) and nans.shape == (0,)
+    # PcSaft.bubble_point keeps the Rust layout rho[n_ok,4] = (rhoV_1, rhoV_2, rhoL_1, rhoL_2) (src/pcsaft.rs:216-231)
+    par = np.array([[[1, 3.5, 150, 0, 0, 0, 0, 0], [1, 3.5, 200, 0, 0, 0, 0, 0]]] * 3, dtype=float)
+    kij = np.array([[-0.15, 0.0]] * 3)
+    T = np.array([150.0, 1000.0, 150.0])  # row 1: far super-critical -> fails
+    rho, status = amd.PcSaft.bubble_point(par, kij, T, np.full(3, 0.5), np.full(3, 1e5))
+    assert status.tolist() == [False, True, False] and rho.shape == (2, 4)
+    want, st = oracle.mix_bubble_dew_root(par, kij, T, np.full(3, 0.5), np.full(3, 1e5), dew=False)
+    assert np.max(np.abs(rho / want[~st] - 1)) < 1e-7
+    rho_d, status_d = amd.PcSaft.dew_point(par, kij, T, np.full(3, 0.5), np.full(3, 1e5))
+    assert rho_d.shape == (2, 4) and status_d.tolist() == [False, True, False]
