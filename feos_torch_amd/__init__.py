@@ -8,5 +8,6 @@ reference) is ``libpcsaft_hip.so`` — hand-written gfx950 kernels behind the C 
 from .native import PcSaft  # noqa: F401  (mirror of the reference's extension class)
 from .pcsaft_pure import PcSaftPure  # noqa: F401
 from .pcsaft_mix import PcSaftMix  # noqa: F401
+from .gc_pcsaft import GcPcSaft, GcPcSaftMix  # noqa: F401
 
 __version__ = "0.1.0"

@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpcsaft_hip.so")
-SOURCES = ["pure_kernels.hip", "mix_kernels.hip"]
+SOURCES = ["pure_kernels.hip", "mix_kernels.hip", "gc_kernels.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"]
 
 

@@ -1,0 +1,275 @@
+// gfx950 kernels + C ABI for the heterosegmented gc-PC-SAFT path (GcPcSaftMix bubble / dew
+// points and derivatives).  One state point per lane.  The per-batch segment / pair tables are
+// staged into LDS by every workgroup; each lane keeps its bond list (d_ab, count) in a
+// lane-strided LDS scratch area (conflict-free) so the hard-chain loop needs no registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pcsaft_hip.h"
+#include "abi_common.hpp"
+#include "gc_model.hpp"
+#include "mix_solver.hpp"
+
+using namespace pcs;
+using namespace pcs_abi;
+
+namespace {
+
+constexpr int GBLOCK = 128;
+constexpr int GJBLOCK = 64;
+
+template <class P>
+struct GcModelT {
+    GcCoef<P> c;
+    template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return gc_a<P, R>(c, r0, r1); }
+    PCS_DEV double packing(double x0, double x1) const { return x0 * re(c.zk[3][0]) + x1 * re(c.zk[3][1]); }
+};
+
+// stage the batch table (S*8 + 3*S*S doubles) into LDS
+__device__ __forceinline__ GcTable stage_table(const double* __restrict__ table, int S, double* lds) {
+    const int nd = gc_table_doubles(S);
+    for (int k = threadIdx.x; k < nd; k += blockDim.x) lds[k] = table[k];
+    __syncthreads();
+    GcTable tb;
+    tb.S = S;
+    tb.seg = lds;
+    tb.E1 = lds + S * 8;
+    tb.E2 = tb.E1 + S * S;
+    tb.K = tb.E2 + S * S;
+    return tb;
+}
+
+template <bool DEW>
+__global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restrict__ table, int S,
+                                                          const unsigned char* __restrict__ rows,
+                                                          const double* __restrict__ phi,
+                                                          const double* __restrict__ temp, const double* __restrict__ z,
+                                                          const double* __restrict__ p_init, int64_t n,
+                                                          double* __restrict__ p_out, double* __restrict__ rho4,
+                                                          uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
+    extern __shared__ double lds[];
+    GcTable tb = stage_table(table, S, lds);
+    double* bonds = lds + gc_table_doubles(S);  // [2][16][GBLOCK]: dab then cnt
+    const int64_t i = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
+    if (i >= n) return;
+    GcModelT<double> m;
+    m.c.bond_dab = bonds + threadIdx.x;
+    m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
+    m.c.stride = GBLOCK;
+    const double T = temp[i];
+    gc_coef<double>(m.c, rows + (size_t)i * GC_ROW_BYTES, tb, phi[2 * i], phi[2 * i + 1], T);
+    MixResult r;
+    bool ok = bubble_dew_solve<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
+    if (p_out) p_out[i] = ok ? r.p * T * P_UNIT : 0.0;
+    if (rho4) {
+        double v0 = DEW ? r.spec0 : r.inc0, v1 = DEW ? r.spec1 : r.inc1;
+        double l0 = DEW ? r.inc0 : r.spec0, l1 = DEW ? r.inc1 : r.spec1;
+        reinterpret_cast<double4*>(rho4)[i] = ok ? make_double4(v0, v1, l0, l1) : make_double4(0.0, 0.0, 0.0, 0.0);
+    }
+    if (iters) iters[i] = ok ? r.iters : -1;
+    status[i] = ok ? 0 : 1;
+}
+
+// GcPcSaftMix.derivatives (feos_torch/gc_pcsaft.py:443-468)
+__global__ __launch_bounds__(GBLOCK) void k_gc_derivatives(const double* __restrict__ table, int S,
+                                                           const unsigned char* __restrict__ rows,
+                                                           const double* __restrict__ phi,
+                                                           const double* __restrict__ temp,
+                                                           const double* __restrict__ rho, int64_t n,
+                                                           double* __restrict__ a, double* __restrict__ p,
+                                                           double* __restrict__ mu, double* __restrict__ v) {
+    extern __shared__ double lds[];
+    GcTable tb = stage_table(table, S, lds);
+    double* bonds = lds + gc_table_doubles(S);
+    const int64_t i = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
+    if (i >= n) return;
+    GcModelT<double> m;
+    m.c.bond_dab = bonds + threadIdx.x;
+    m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
+    m.c.stride = GBLOCK;
+    gc_coef<double>(m.c, rows + (size_t)i * GC_ROW_BYTES, tb, phi[2 * i], phi[2 * i + 1], temp[i]);
+    PhaseEval e = phase_eval(m, rho[2 * i], rho[2 * i + 1]);
+    if (a) a[i] = e.a;
+    if (p) p[i] = e.p();
+    if (mu) { mu[2 * i] = e.g0; mu[2 * i + 1] = e.g1; }
+    if (v) {
+        double d0 = e.dp0(), d1 = e.dp1();
+        double den = 1.0 / (e.r0 * d0 + e.r1 * d1);
+        v[2 * i] = d0 * den;
+        v[2 * i + 1] = d1 * den;
+    }
+}
+
+// gradient of the bubble / dew pressure w.r.t. the six dispersion aggregates and T (implicit-
+// function form, see mix_jacobian.hpp); k_ab and phi enter the model only through the
+// aggregates (feos_torch/gc_pcsaft.py:181-194), the host chains them (gc_pcsaft.py in this package).
+constexpr int GC_DIRS = 7;   // A00, A01, A11, B00, B01, B11, T
+constexpr int GC_CHUNK = 2;
+
+__global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* __restrict__ table, int S,
+                                                         const unsigned char* __restrict__ rows,
+                                                         const double* __restrict__ phi,
+                                                         const double* __restrict__ temp,
+                                                         const double* __restrict__ rho4, int64_t n,
+                                                         double* __restrict__ jac, double* __restrict__ agg) {
+    typedef DN<double, GC_CHUNK> G;
+    typedef T1<G> R;
+    extern __shared__ double lds[];
+    GcTable tb = stage_table(table, S, lds);
+    double* bonds = lds + gc_table_doubles(S);                       // double model: [2*MAXE dab][2*MAXE cnt] x block
+    G* gbonds = reinterpret_cast<G*>(bonds + 4 * GC_MAXE * GJBLOCK);  // dual model dab
+    const int64_t i = (int64_t)blockIdx.x * GJBLOCK + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* row = rows + (size_t)i * GC_ROW_BYTES;
+    const double T = temp[i], ph0 = phi[2 * i], ph1 = phi[2 * i + 1];
+    const double4 r4 = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
+    const double s0 = dew ? r4.x : r4.z, s1 = dew ? r4.y : r4.w, i0 = dew ? r4.z : r4.x, i1 = dew ? r4.w : r4.y;
+    GcModelT<double> m;
+    m.c.bond_dab = bonds + threadIdx.x;
+    m.c.bond_cnt = bonds + 2 * GC_MAXE * GJBLOCK + threadIdx.x;
+    m.c.stride = GJBLOCK;
+    gc_coef<double>(m.c, row, tb, ph0, ph1, T);
+    if (agg) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { agg[6 * i + k] = m.c.A[k]; agg[6 * i + 3 + k] = m.c.B[k]; }
+    }
+    PhaseEval s = phase_eval(m, s0, s1);
+    PhaseEval nn = phase_eval(m, i0, i1);
+    const double rs = s0 + s1, z0 = s0 / rs, z1 = s1 / rs;
+    double J[3][3];
+    J[0][0] = rs * (z0 * (1.0 / s.r0 + s.h00) + z1 * s.h01);
+    J[1][0] = rs * (z0 * s.h01 + z1 * (1.0 / s.r1 + s.h11));
+    J[2][0] = rs * (z0 * s.dp0() + z1 * s.dp1());
+    J[0][1] = -i0 * (1.0 / i0 + nn.h00);
+    J[1][1] = -i0 * nn.h01;
+    J[2][1] = -i0 * nn.dp0();
+    J[0][2] = -i1 * nn.h01;
+    J[1][2] = -i1 * (1.0 / i1 + nn.h11);
+    J[2][2] = -i1 * nn.dp1();
+    double A[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) A[r][cc] = J[cc][r];
+        A[r][3] = 0.0;
+    }
+    if (dew) {
+        A[0][3] = J[2][0];
+    } else {
+        A[1][3] = -J[2][1];
+        A[2][3] = -J[2][2];
+    }
+    double w[3];
+    const bool ok = solve3(A, w);
+    const double p_red = dew ? s.p() : nn.p();
+    double g[GC_DIRS];
+    constexpr int NPASS = (GC_DIRS + GC_CHUNK - 1) / GC_CHUNK;
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; pass++) {
+        const int d0 = pass * GC_CHUNK;
+        G gT;
+        gT.v = T;
+#pragma unroll
+        for (int j = 0; j < GC_CHUNK; j++) gT.e[j] = (d0 + j == 6) ? 1.0 : 0.0;
+        GcCoef<G> c;
+        c.bond_dab = gbonds + threadIdx.x;
+        c.bond_cnt = m.c.bond_cnt;  // counts are shared (written identically)
+        c.stride = GJBLOCK;
+        gc_coef<G>(c, row, tb, ph0, ph1, gT);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int j = 0; j < GC_CHUNK; j++) {
+                if (d0 + j == k) c.A[k].e[j] += 1.0;
+                if (d0 + j == 3 + k) c.B[k].e[j] += 1.0;
+            }
+        }
+        R aS = gc_a<G, R>(c, R(G(s0), G(1.0), G(0.0)), R(G(s1), G(0.0), G(1.0)));
+        R aI = gc_a<G, R>(c, R(G(i0), G(1.0), G(0.0)), R(G(i1), G(0.0), G(1.0)));
+#pragma unroll
+        for (int j = 0; j < GC_CHUNK; j++) {
+            double dF0 = aS.g0.e[j] - aI.g0.e[j];
+            double dF1 = aS.g1.e[j] - aI.g1.e[j];
+            double dpS = -aS.v.e[j] + s0 * aS.g0.e[j] + s1 * aS.g1.e[j];
+            double dpI = -aI.v.e[j] + i0 * aI.g0.e[j] + i1 * aI.g1.e[j];
+            double dp = (dew ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
+            double val = dp * T * P_UNIT;
+            if (d0 + j == 6) val += p_red * P_UNIT;
+            if (!ok) val = __builtin_nan("");
+#pragma unroll
+            for (int d = 0; d < GC_DIRS; d++)
+                if (d == d0 + j) g[d] = val;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < GC_DIRS; k++) jac[GC_DIRS * i + k] = g[k];
+}
+
+size_t gc_lds_bytes(int S, int block, int per_thread_doubles) {
+    return sizeof(double) * ((size_t)(S * 8 + 3 * S * S) + (size_t)per_thread_doubles * block);
+}
+
+int gc_check(int S, int64_t n) {
+    if (int e = check_n(n)) return e;
+    if (S < 1 || S > GC_MAXS) return fail_msg("gc: number of segment types must be in [1, 32]");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t pcs_gc_table_doubles(int S) { return (int64_t)S * 8 + 3 * (int64_t)S * S; }
+
+int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                      const double* z, const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status,
+                      int32_t* iters, void* stream) {
+    g_err[0] = 0;
+    if (int e = gc_check(S, n)) return e;
+    if (n == 0) return 0;
+    if (!table || !rows || !phi || !temp || !z || !p_init || !status) return fail_msg("pcs_gc_bubble_dew: null required pointer");
+    const unsigned grid = (unsigned)((n + GBLOCK - 1) / GBLOCK);
+    const size_t lds = gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE);
+    hipStream_t s = as_stream(stream);
+    if (dew)
+        hipLaunchKernelGGL(k_gc_bubble_dew<true>, dim3(grid), dim3(GBLOCK), lds, s, table, S, rows, phi, temp, z, p_init, n, p_out,
+                           rho4, status, iters);
+    else
+        hipLaunchKernelGGL(k_gc_bubble_dew<false>, dim3(grid), dim3(GBLOCK), lds, s, table, S, rows, phi, temp, z, p_init, n,
+                           p_out, rho4, status, iters);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_gc_bubble_dew launch", e);
+    return 0;
+}
+
+int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                       const double* rho, int64_t n, double* a, double* p, double* mu, double* v, void* stream) {
+    g_err[0] = 0;
+    if (int e = gc_check(S, n)) return e;
+    if (n == 0) return 0;
+    if (!table || !rows || !phi || !temp || !rho) return fail_msg("pcs_gc_derivatives: null required pointer");
+    const unsigned grid = (unsigned)((n + GBLOCK - 1) / GBLOCK);
+    hipLaunchKernelGGL(k_gc_derivatives, dim3(grid), dim3(GBLOCK), gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE), as_stream(stream),
+                       table, S, rows, phi, temp, rho, n, a, p, mu, v);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_gc_derivatives launch", e);
+    return 0;
+}
+
+int pcs_gc_jacobian(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                    const double* rho4, int64_t n, double* jac, double* agg, void* stream) {
+    g_err[0] = 0;
+    if (int e = gc_check(S, n)) return e;
+    if (n == 0) return 0;
+    if (!table || !rows || !phi || !temp || !rho4 || !jac) return fail_msg("pcs_gc_jacobian: null required pointer");
+    const unsigned grid = (unsigned)((n + GJBLOCK - 1) / GJBLOCK);
+    // double model: 4*MAXE doubles per thread; dual model dab: 2*MAXE * (1 + GC_CHUNK) doubles per thread
+    const size_t lds = gc_lds_bytes(S, GJBLOCK, 4 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK));
+    hipLaunchKernelGGL(k_gc_jacobian, dim3(grid), dim3(GJBLOCK), lds, as_stream(stream), dew, table, S, rows, phi, temp,
+                       rho4, n, jac, agg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_gc_jacobian launch", e);
+    return 0;
+}
+
+}  // extern "C"

@@ -36,6 +36,56 @@ struct MixCoef {
     P S[3];       // (sigma_i sigma_j)^1.5 sqrt(kappa_i kappa_j) (exp(eps_ij/T) - 1)   (:506-522)
 };
 
+// Pair / triplet polynomial coefficients of the Gross-Vrabec dipole term for a binary mixture
+// (feos_torch/pcsaft_mix.py:156-208 == feos_torch/gc_pcsaft.py:255-307) with every constant folded:
+//   phi2 = sum_pairs r_i r_j pj[pair](eta),  phi3 = sum_triplets r_i r_j r_k tj[t](eta),
+//   dipole = phi2^2 / (phi2 - phi3).   m, sig, eps = (molecule-level) m, sigma, epsilon_k;
+//   mu2t_i = the reference's `mu2_term` of component i.
+template <class P>
+PCS_DEV void dipole_coefficients(P pj[3][5], P tj[4][4], const P* m, const P* sig, const P* eps, const P* mu2t, const P& rT) {
+    P mc[2], s3[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        mc[i] = (re(m[i]) > 2.0) ? P(2.0) : m[i];
+        s3[i] = sig[i] * sig[i] * sig[i];
+    }
+    P s01 = 0.5 * (sig[0] + sig[1]);
+    P s01_3 = s01 * s01 * s01;
+    P e00 = eps[0] * rT, e11 = eps[1] * rT;
+    P et01 = d_sqrt(eps[0] * eps[1]) * rT;  // no k_ij here (:172)
+#pragma unroll
+    for (int pr = 0; pr < 3; pr++) {
+        const int i = (pr == 2) ? 1 : 0, j = (pr == 0) ? 0 : 1;
+        P mij = (i == j) ? mc[i] : d_sqrt(mc[0] * mc[1]);
+        P rm = d_recip(mij);
+        P m1 = (mij - 1.0) * rm;
+        P m2 = m1 * ((mij - 2.0) * rm);
+        P et = (pr == 0) ? e00 : (pr == 2 ? e11 : et01);
+        P sij3 = (pr == 0) ? s3[0] : (pr == 2 ? s3[1] : s01_3);
+        P pref = (mu2t[i] * mu2t[j]) * d_recip(sij3) * (-PI * ((i == j) ? 1.0 : 2.0));
+#pragma unroll
+        for (int n = 0; n < 5; n++) {
+            P a = AD[n][0] + m1 * AD[n][1] + m2 * AD[n][2];
+            if (n < 3) a = a + (BD[n][0] + m1 * BD[n][1] + m2 * BD[n][2]) * et;
+            pj[pr][n] = a * pref;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {  // triplets 000, 001, 011, 111
+        const int n1 = t;
+        P prod = (n1 == 0) ? mc[0] * mc[0] * mc[0] : (n1 == 1) ? mc[0] * mc[0] * mc[1] : (n1 == 2) ? mc[0] * mc[1] * mc[1] : mc[1] * mc[1] * mc[1];
+        P mijk = (n1 == 0) ? mc[0] : (n1 == 3) ? mc[1] : d_cbrt(prod);
+        P rm = d_recip(mijk);
+        P m1 = (mijk - 1.0) * rm;
+        P m2 = m1 * ((mijk - 2.0) * rm);
+        P sprod = (n1 == 0) ? s3[0] : (n1 == 3) ? s3[1] : (n1 == 1) ? sig[0] * (s01 * s01) : (s01 * s01) * sig[1];
+        P muprod = (n1 == 0) ? mu2t[0] * mu2t[0] * mu2t[0] : (n1 == 1) ? mu2t[0] * mu2t[0] * mu2t[1] : (n1 == 2) ? mu2t[0] * mu2t[1] * mu2t[1] : mu2t[1] * mu2t[1] * mu2t[1];
+        P pref = muprod * d_recip(sprod) * (-PI_SQ_43 * ((n1 == 0 || n1 == 3) ? 1.0 : 3.0));
+#pragma unroll
+        for (int n = 0; n < 4; n++) tj[t][n] = (CD[n][0] + m1 * CD[n][1] + m2 * CD[n][2]) * pref;
+    }
+}
+
 // par = [2][8] rows (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb); kij0 = k_ij,
 // kij1 = explicit eps_AiBj/k or 0 (src/pcsaft.rs:163).
 template <class P>
@@ -75,46 +125,7 @@ PCS_DEV void mix_coef(MixCoef<P>& c, const P* par, const P& kij0, const P& kij1,
 
     // dipoles (:156-208)
     c.polar = (re(par[3]) != 0.0) || (re(par[8 + 3]) != 0.0);
-    if (c.polar) {
-        P mc[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) mc[i] = (re(c.m[i]) > 2.0) ? P(2.0) : c.m[i];
-        P et01 = d_sqrt(eps[0] * eps[1]) * rT;  // no k_ij here (:172)
-        // pairs
-#pragma unroll
-        for (int pr = 0; pr < 3; pr++) {
-            const int i = (pr == 2) ? 1 : 0, j = (pr == 0) ? 0 : 1;
-            P mij = (i == j) ? mc[i] : d_sqrt(mc[0] * mc[1]);
-            P rm = d_recip(mij);
-            P m1 = (mij - 1.0) * rm;
-            P m2 = m1 * ((mij - 2.0) * rm);
-            P et = (pr == 0) ? e00 : (pr == 2 ? e11 : et01);
-            P sij3 = (pr == 0) ? s3[0] : (pr == 2 ? s3[1] : s01_3);
-            P pref = (mu2t[i] * mu2t[j]) * d_recip(sij3) * (-PI * ((i == j) ? 1.0 : 2.0));
-#pragma unroll
-            for (int n = 0; n < 5; n++) {
-                P a = AD[n][0] + m1 * AD[n][1] + m2 * AD[n][2];
-                if (n < 3) a = a + (BD[n][0] + m1 * BD[n][1] + m2 * BD[n][2]) * et;
-                c.pj[pr][n] = a * pref;
-            }
-        }
-        // triplets 000, 001, 011, 111
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int n1 = t;  // number of component-1 members
-            P prod = (n1 == 0) ? mc[0] * mc[0] * mc[0] : (n1 == 1) ? mc[0] * mc[0] * mc[1] : (n1 == 2) ? mc[0] * mc[1] * mc[1] : mc[1] * mc[1] * mc[1];
-            P mijk = (n1 == 0) ? mc[0] : (n1 == 3) ? mc[1] : d_cbrt(prod);
-            P rm = d_recip(mijk);
-            P m1 = (mijk - 1.0) * rm;
-            P m2 = m1 * ((mijk - 2.0) * rm);
-            // sigma_ij sigma_ik sigma_jk and the mu2 product
-            P sprod = (n1 == 0) ? s3[0] : (n1 == 3) ? s3[1] : (n1 == 1) ? sig[0] * (s01 * s01) : (s01 * s01) * sig[1];
-            P muprod = (n1 == 0) ? mu2t[0] * mu2t[0] * mu2t[0] : (n1 == 1) ? mu2t[0] * mu2t[0] * mu2t[1] : (n1 == 2) ? mu2t[0] * mu2t[1] * mu2t[1] : mu2t[1] * mu2t[1] * mu2t[1];
-            P pref = muprod * d_recip(sprod) * (-PI_SQ_43 * ((n1 == 0 || n1 == 3) ? 1.0 : 3.0));
-#pragma unroll
-            for (int n = 0; n < 4; n++) c.tj[t][n] = (CD[n][0] + m1 * CD[n][1] + m2 * CD[n][2]) * pref;
-        }
-    }
+    if (c.polar) dipole_coefficients<P>(c.pj, c.tj, c.m, sig, eps, mu2t, rT);
 
     // association (:118-152)
     const int associating = (re(c.na[0]) + re(c.nb[0]) != 0.0) + (re(c.na[1]) + re(c.nb[1]) != 0.0);
@@ -190,34 +201,31 @@ PCS_DEV void induced_step(const X& xa, const X& na0, const X& na1, const X& nb0,
 template <class R>
 PCS_DEV R lift_real(double x) { return R(x); }
 
-// stage 2: a(rho_0, rho_1) at fixed coefficients
-template <class P, class R>
-PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
+// Packing-fraction quantities shared by all contributions
+template <class R>
+struct Packing {
+    R zeta2, zeta3, z3m1, z3m2, omz;
+};
+
+// hard sphere (:56-60) + dispersion (:69-106) + dipoles (:156-208) for any coefficient struct C that
+// provides m[2], zk[4][2], A[3], B[3], polar, pj, tj (MixCoef, GcCoef).  Fills `pk`.
+template <class C, class R>
+PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
     R zeta0 = r0 * c.zk[0][0] + r1 * c.zk[0][1];
     R zeta1 = r0 * c.zk[1][0] + r1 * c.zk[1][1];
     R zeta2 = r0 * c.zk[2][0] + r1 * c.zk[2][1];
     R zeta3 = r0 * c.zk[3][0] + r1 * c.zk[3][1];
-    R z3m1 = d_recip(1.0 - zeta3);
+    R omz = 1.0 - zeta3;
+    R z3m1 = d_recip(omz);
     R z3m2 = z3m1 * z3m1;
     R zeta23 = zeta2 * d_recip(zeta3);
-    R l13 = d_log(1.0 - zeta3);
+    R l13 = d_log(omz);
+    pk.zeta2 = zeta2; pk.zeta3 = zeta3; pk.z3m1 = z3m1; pk.z3m2 = z3m2; pk.omz = omz;
 
-    // hard sphere (:56-60)
+    // hard sphere
     R a = (6.0 / PI) * (3.0 * (zeta1 * zeta2) * z3m1 + (zeta2 * zeta2) * z3m2 * zeta23 + (zeta2 * (zeta23 * zeta23) - zeta0) * l13);
 
-    // hard chain (:63-65):  g_i = 1/(1-z3) + 1.5 d_i c + 0.5 d_i^2 c^2 (1 - z3),  c = z2/(1-z3)^2
-    R cc = zeta2 * z3m2;
-    R omz = 1.0 - zeta3;
-    {
-        R cd = cc * c.d[0];
-        R g = z3m1 + 1.5 * cd + 0.5 * ((cd * cd) * omz);
-        a = a - (r0 * c.mm1[0]) * d_log(g);
-        cd = cc * c.d[1];
-        g = z3m1 + 1.5 * cd + 0.5 * ((cd * cd) * omz);
-        a = a - (r1 * c.mm1[1]) * d_log(g);
-    }
-
-    // dispersion (:69-106)
+    // dispersion
     R r00 = r0 * r0, r01 = r0 * r1, r11 = r1 * r1;
     R rs = r0 + r1;
     R mbar = (r0 * c.m[0] + r1 * c.m[1]) * d_recip(rs);
@@ -234,12 +242,32 @@ PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
     R rho2mix = r00 * c.B[0] + r01 * c.B[1] + r11 * c.B[2];
     a = a - PI * (2.0 * (rho1mix * I1) + (rho2mix * (C1 * I2)) * mbar);
 
-    // dipoles (:156-208)
+    // dipoles
     if (c.polar) {
         R phi2 = r00 * horner<5>(c.pj[0], zeta3) + r01 * horner<5>(c.pj[1], zeta3) + r11 * horner<5>(c.pj[2], zeta3);
         R phi3 = (r00 * r0) * horner<4>(c.tj[0], zeta3) + (r00 * r1) * horner<4>(c.tj[1], zeta3) +
                  (r0 * r11) * horner<4>(c.tj[2], zeta3) + (r11 * r1) * horner<4>(c.tj[3], zeta3);
         a = a + (phi2 * phi2) * d_recip(phi2 - phi3);
+    }
+    return a;
+}
+
+// stage 2: a(rho_0, rho_1) at fixed coefficients
+template <class P, class R>
+PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
+    Packing<R> pk;
+    R a = core_terms(c, r0, r1, pk);
+    const R &zeta2 = pk.zeta2, &z3m1 = pk.z3m1;
+
+    // hard chain (:63-65):  g_i = 1/(1-z3) + 1.5 d_i c + 0.5 d_i^2 c^2 (1 - z3),  c = z2/(1-z3)^2
+    R cc = zeta2 * pk.z3m2;
+    {
+        R cd = cc * c.d[0];
+        R g = z3m1 + 1.5 * cd + 0.5 * ((cd * cd) * pk.omz);
+        a = a - (r0 * c.mm1[0]) * d_log(g);
+        cd = cc * c.d[1];
+        g = z3m1 + 1.5 * cd + 0.5 * ((cd * cd) * pk.omz);
+        a = a - (r1 * c.mm1[1]) * d_log(g);
     }
 
     // association (:118-152)

@@ -1,0 +1,244 @@
+"""``GcPcSaftMix`` / ``GcPcSaft`` — drop-ins for the reference's heterosegmented gc-PC-SAFT classes
+(feos_torch/gc_pcsaft.py:13-528, src/gc_pcsaft.rs:15-171) backed by the gfx950 kernels.
+
+Constructor arguments, method names, return order ``(pressure [Pa], nans)`` and the mutate-on-call
+semantics follow the reference.  Instead of its dense ``[N,2,S]`` / ``[N,2,S,S]`` tensors the
+molecule structures are encoded once into 80 bytes per row (see include/pcsaft_hip.h); identical
+molecules are encoded once and re-used.
+
+Gradients: ``k_ab`` (the tensors inside ``binary_segment_records``), ``phi`` and ``temperature``.
+k_ab and phi enter the model only through the six dispersion aggregates of a row
+(feos_torch/gc_pcsaft.py:177-194); the kernel returns dp/d(aggregates) and this module chains
+them with two [S,N]x[N,S] products.  (The reference's own d/dphi is NaN whenever the segment
+table holds a segment with epsilon_k = 0 such as '>C<' — sqrt(0) under autograd.)
+Segment-parameter gradients are not provided yet.
+"""
+import numpy as np
+import torch
+
+from . import native
+
+MAXE = 8  # distinct segment types / bond types per molecule in the 80-byte row encoding
+
+
+def _encode_molecule(segs, bonds, idx):
+    """40 bytes: seg_id[8], seg_cnt[8], bond_a[8], bond_b[8], bond_cnt[8] (counts 0 = unused)."""
+    ids = [idx[s] for s in segs]
+    scount = {}
+    for a in ids:
+        scount[a] = scount.get(a, 0) + 1
+    bcount = {}
+    for i, j in bonds:
+        a, b = ids[i], ids[j]
+        key = (a, b) if a >= b else (b, a)  # larger index first (feos_torch/gc_pcsaft.py:35)
+        bcount[key] = bcount.get(key, 0) + 1
+    if len(scount) > MAXE or len(bcount) > MAXE:
+        raise ValueError(f"a molecule may use at most {MAXE} distinct segment types and {MAXE} distinct bond types")
+    if max(list(scount.values()) + list(bcount.values()) + [0]) > 255:
+        raise ValueError("segment / bond multiplicity above 255")
+    out = np.zeros(40, dtype=np.uint8)
+    for k, (a, c) in enumerate(sorted(scount.items())):
+        out[k] = a
+        out[8 + k] = c
+    for k, ((a, b), c) in enumerate(sorted(bcount.items())):
+        out[16 + k] = a
+        out[24 + k] = b
+        out[32 + k] = c
+    return out
+
+
+def encode_rows(segment_identifier, segment_lists, bond_lists):
+    """[N, 80] uint8 row encoding (layout of include/pcsaft_hip.h)."""
+    idx = {s: i for i, s in enumerate(segment_identifier)}
+    cache = {}
+    n = len(segment_lists)
+    rows = np.zeros((n, 80), dtype=np.uint8)
+    for r in range(n):
+        for c in range(2):
+            key = (tuple(segment_lists[r][c]), tuple(map(tuple, bond_lists[r][c])))
+            enc = cache.get(key)
+            if enc is None:
+                enc = _encode_molecule(segment_lists[r][c], bond_lists[r][c], idx)
+                cache[key] = enc
+            rows[r, 8 * c:8 * c + 8] = enc[0:8]
+            rows[r, 16 + 8 * c:16 + 8 * c + 8] = enc[8:16]
+            rows[r, 32 + 8 * c:32 + 8 * c + 8] = enc[16:24]
+            rows[r, 48 + 8 * c:48 + 8 * c + 8] = enc[24:32]
+            rows[r, 64 + 8 * c:64 + 8 * c + 8] = enc[32:40]
+    return rows
+
+
+def build_table(seg, kab):
+    """seg [S,8], kab [S,S] (detached, any device) -> flat table [S*8 + 3*S*S] (see include/pcsaft_hip.h)."""
+    sigma, eps = seg[:, 1], seg[:, 2]
+    s3 = (0.5 * (sigma[:, None] + sigma[None, :])) ** 3
+    ee = eps[:, None] * eps[None, :]
+    return torch.cat([seg.reshape(-1), (ee.sqrt() * s3).reshape(-1), (ee * s3).reshape(-1), (1.0 - kab).reshape(-1)]).contiguous()
+
+
+class _GcBubbleDew(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dew, model, kab, phi, temperature, molefracs, pressure):
+        dev = model.device
+        table = build_table(model.seg.to(dev), kab.detach().to(dev, torch.float64))
+        ph = native._prep(phi, dev, (2,))
+        T = native._prep(temperature, dev)
+        r = native.gc_bubble_dew(table, model.S, model.rows, ph, T, native._prep(molefracs, dev),
+                                 native._prep(pressure, dev), dew)
+        nans = r["status"]
+        ok = ~nans
+        value = r["p"][ok]
+        needs = [ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]]
+        if any(needs):
+            rows_ok = model.rows[ok]
+            jac, agg = native.gc_jacobian(table, model.S, rows_ok, ph[ok], T[ok], r["rho4"][ok], dew)
+            ctx.save_for_backward(jac, agg, ok, rows_ok, ph[ok], T[ok], table)
+        ctx.needs = needs
+        ctx.S = model.S
+        ctx.n = T.shape[0]
+        ctx.devs = (kab.device, phi.device, temperature.device)
+        out_device = phi.device
+        nans = nans.to(out_device)
+        ctx.mark_non_differentiable(nans)
+        return value.to(out_device), nans
+
+    @staticmethod
+    def backward(ctx, g_value, _g):
+        jac, agg, ok, rows, ph, T, table = ctx.saved_tensors
+        S, n = ctx.S, ctx.n
+        g = g_value.to(jac.device)
+        gk = gphi = gT = None
+        if ctx.needs[0]:
+            # m-weighted dense counts of the converged rows, built on the device from the row encoding
+            seg_m = table[: S * 8].view(S, 8)[:, 0]
+            E1 = table[S * 8: S * 8 + S * S].view(S, S)
+            E2 = table[S * 8 + S * S: S * 8 + 2 * S * S].view(S, S)
+            K = table[S * 8 + 2 * S * S:].view(S, S)
+            M = []
+            for c in range(2):
+                ids = rows[:, 8 * c:8 * c + 8].long()
+                cnt = rows[:, 16 + 8 * c:16 + 8 * c + 8].to(torch.float64)
+                Mc = torch.zeros((rows.shape[0], S), dtype=torch.float64, device=rows.device)
+                Mc.scatter_add_(1, ids, cnt * seg_m[ids])
+                M.append(Mc)
+            pp = ph[:, 0] * ph[:, 1]
+            w1 = g * jac[:, 1] * 2.0 * pp.sqrt() / T          # d A01 / d K_ab = w-part * m0a m1b E1_ab
+            w2 = g * jac[:, 4] * 4.0 * pp / (T * T)            # d B01 / d K_ab = w-part * m0a m1b E2_ab K_ab
+            G1 = M[0].t() @ (w1[:, None] * M[1])
+            G2 = M[0].t() @ (w2[:, None] * M[1])
+            gk = (-(E1 * G1) - (E2 * K) * G2).to(ctx.devs[0])  # K = 1 - k_ab
+        if ctx.needs[1]:
+            gphi = torch.zeros((n, 2), dtype=torch.float64, device=jac.device)
+            A00, A01, A11, B00, B01, B11 = (agg[:, k] for k in range(6))
+            d0 = jac[:, 0] * A00 + 0.5 * jac[:, 1] * A01 + 2.0 * jac[:, 3] * B00 + jac[:, 4] * B01
+            d1 = jac[:, 2] * A11 + 0.5 * jac[:, 1] * A01 + 2.0 * jac[:, 5] * B11 + jac[:, 4] * B01
+            gphi[ok] = torch.stack([g * d0 / ph[:, 0], g * d1 / ph[:, 1]], dim=1)
+            gphi = gphi.to(ctx.devs[1])
+        if ctx.needs[2]:
+            gT = torch.zeros(n, dtype=torch.float64, device=jac.device)
+            gT[ok] = g * jac[:, 6]
+            gT = gT.to(ctx.devs[2])
+        return None, None, gk, gphi, gT, None, None
+
+
+class GcPcSaftMix:
+    def __init__(self, segment_identifier, parameter, segment_lists, bond_lists, binary_segment_records, phi=None):
+        """Arguments as the reference (feos_torch/gc_pcsaft.py:14-22): segment identifiers [S], the
+        8 segment parameter vectors (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb), per-row
+        [segments of molecule 1, of molecule 2], per-row bond index pairs, [(s1, s2, k_ab)], phi [N,2]."""
+        if any(isinstance(p, torch.Tensor) and p.requires_grad for p in parameter):
+            raise NotImplementedError("gradients w.r.t. segment parameters are not provided yet (k_ab, phi, T are)")
+        self.segment_identifier = list(segment_identifier)
+        self.S = len(self.segment_identifier)
+        if self.S > 32:
+            raise ValueError("at most 32 segment types per table")
+        self.device = native._dev()
+        self.seg = torch.stack([torch.as_tensor(p, dtype=torch.float64).detach().cpu() for p in parameter], dim=1).contiguous()
+        n = len(segment_lists)
+        rows = encode_rows(self.segment_identifier, segment_lists, bond_lists)
+        # "Only up to one associating segment per component is allowed!" (:76-80)
+        is_assoc = (np.sign(self.seg[:, 4].numpy() * self.seg[:, 5].numpy()) != 0)
+        for c in range(2):
+            cnt = (rows[:, 16 + 8 * c:16 + 8 * c + 8] * is_assoc[rows[:, 8 * c:8 * c + 8]]).sum(axis=1)
+            if np.any(cnt > 1):
+                raise Exception("Only up to one associating segment per component is allowed!")
+        self.rows = torch.from_numpy(rows).to(self.device)
+        idx = {s: i for i, s in enumerate(self.segment_identifier)}
+        # symmetric k_ab matrix built exactly as the reference does (:60-63), keeps autograd history
+        self.kab = torch.zeros((self.S, self.S), dtype=torch.float64)
+        for s1, s2, k in binary_segment_records:
+            self.kab[idx[s1], idx[s2]] = k
+            self.kab[idx[s2], idx[s1]] = k
+        self.phi = torch.ones((n, 2), dtype=torch.float64) if phi is None else phi
+        self.gc_pcsaft = GcPcSaft._from_model(self)
+
+    def _table(self):
+        return build_table(self.seg.to(self.device), self.kab.detach().to(self.device))
+
+    def helmholtz_energy_density(self, temperature, density, kab=None):
+        return self.derivatives(temperature, density)[0][:, None]
+
+    def derivatives(self, temperature, density):
+        """(a, p, mu [N,2], v [N,2]) (:443-468).  Forward only."""
+        a, p, mu, v = native.gc_derivatives(self._table(), self.S, self.rows, self.phi, temperature, density)
+        dev = self.phi.device
+        return a.to(dev), p.to(dev), mu.to(dev), v.to(dev)
+
+    def bubble_point(self, temperature, liquid_molefracs, pressure):
+        """(p [Pa], nans) (:470-490)."""
+        value, nans = _GcBubbleDew.apply(False, self, self.kab, self.phi, temperature, liquid_molefracs, pressure)
+        self.reduce(nans)
+        return value, nans
+
+    def dew_point(self, temperature, vapor_molefracs, pressure):
+        """(p [Pa], nans) (:492-512)."""
+        value, nans = _GcBubbleDew.apply(True, self, self.kab, self.phi, temperature, vapor_molefracs, pressure)
+        self.reduce(nans)
+        return value, nans
+
+    def reduce(self, nans):
+        """Drop failed rows from the model (:514-528)."""
+        self.rows = self.rows[~nans.to(self.rows.device)]
+        self.phi = self.phi[~nans.to(self.phi.device)]
+
+
+class GcPcSaft:
+    """Mirror of the reference's Rust pyclass ``GcPcSaft`` (src/gc_pcsaft.rs:15-99): built from
+    segment records, per-row molecule structures, binary segment records and phi; ``bubble_point``
+    / ``dew_point`` take numpy arrays and return ``(rho[n_ok,4], status[N])``."""
+
+    def __init__(self, segment_records, segments, bonds, binary_segment_records, phi):
+        ident = [s for s, _ in segment_records]
+        par = np.stack([np.asarray(v, dtype=np.float64) for _, v in segment_records], axis=0)
+        self.S = len(ident)
+        self.device = native._dev()
+        self.seg = torch.from_numpy(par).contiguous()
+        self.rows = torch.from_numpy(encode_rows(ident, segments, bonds)).to(self.device)
+        kab = torch.zeros((self.S, self.S), dtype=torch.float64)
+        idx = {s: i for i, s in enumerate(ident)}
+        for s1, s2, k in binary_segment_records:
+            kab[idx[s1], idx[s2]] = float(k)
+            kab[idx[s2], idx[s1]] = float(k)
+        self.table = build_table(self.seg.to(self.device), kab.to(self.device))
+        self.phi = torch.as_tensor(np.asarray(phi, dtype=np.float64))
+
+    @classmethod
+    def _from_model(cls, model):
+        obj = cls.__new__(cls)
+        obj.S, obj.device, obj.seg, obj.rows = model.S, model.device, model.seg, model.rows
+        obj.table = model._table()
+        obj.phi = model.phi.detach()
+        return obj
+
+    def _solve(self, temperature, molefracs, pressure, dew):
+        t, x, p = (native._as_f64(v, 1) for v in (temperature, molefracs, pressure))
+        r = native.gc_bubble_dew(self.table, self.S, self.rows, self.phi, torch.from_numpy(t), torch.from_numpy(x),
+                                 torch.from_numpy(p), dew)
+        status = r["status"].cpu().numpy()
+        return r["rho4"].cpu().numpy()[~status], status
+
+    def bubble_point(self, temperature, liquid_molefracs, pressure):
+        return self._solve(temperature, liquid_molefracs, pressure, False)
+
+    def dew_point(self, temperature, vapor_molefracs, pressure):
+        return self._solve(temperature, vapor_molefracs, pressure, True)

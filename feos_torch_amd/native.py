@@ -278,3 +278,64 @@ def mix_jacobian(params, kij, temperature, rho4, dew):
                                 _lib.ptr(rho4), n, _lib.ptr(jac), _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_mix_jacobian")
     return jac
+
+
+# ------------------------------------------------------------------------------------------
+# heterosegmented gc-PC-SAFT
+# ------------------------------------------------------------------------------------------
+def gc_bubble_dew(table, S, rows, phi, temperature, molefracs, pressure, dew, want_iters=False):
+    """table [S*8+3*S*S] f64, rows [n,80] u8 (include/pcsaft_hip.h).  -> dict(p, rho4, status, iters)."""
+    device = table.device
+    phi = _prep(phi, device, (2,))
+    temperature = _prep(temperature, device)
+    molefracs = _prep(molefracs, device)
+    pressure = _prep(pressure, device)
+    n = temperature.shape[0]
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        p = torch.empty(n, dtype=_F64, device=device)
+        rho4 = torch.empty((n, 4), dtype=_F64, device=device)
+        status = torch.empty(n, dtype=torch.uint8, device=device)
+        iters = torch.empty(n, dtype=torch.int32, device=device) if want_iters else None
+        rc = L.pcs_gc_bubble_dew(int(bool(dew)), _lib.ptr(table), int(S), _lib.ptr(rows), _lib.ptr(phi),
+                                 _lib.ptr(temperature), _lib.ptr(molefracs), _lib.ptr(pressure), n, _lib.ptr(p),
+                                 _lib.ptr(rho4), _lib.ptr(status), _lib.ptr(iters), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_gc_bubble_dew")
+    return {"p": p, "rho4": rho4, "status": status.bool(), "iters": iters}
+
+
+def gc_derivatives(table, S, rows, phi, temperature, density):
+    device = table.device
+    phi = _prep(phi, device, (2,))
+    temperature = _prep(temperature, device)
+    density = _prep(density, device, (2,))
+    n = temperature.shape[0]
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        a = torch.empty(n, dtype=_F64, device=device)
+        p = torch.empty(n, dtype=_F64, device=device)
+        mu = torch.empty((n, 2), dtype=_F64, device=device)
+        v = torch.empty((n, 2), dtype=_F64, device=device)
+        rc = L.pcs_gc_derivatives(_lib.ptr(table), int(S), _lib.ptr(rows), _lib.ptr(phi), _lib.ptr(temperature),
+                                  _lib.ptr(density), n, _lib.ptr(a), _lib.ptr(p), _lib.ptr(mu), _lib.ptr(v),
+                                  _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_gc_derivatives")
+    return a, p, mu, v
+
+
+def gc_jacobian(table, S, rows, phi, temperature, rho4, dew):
+    """-> jac [n,7] = dp/d(A00, A01, A11, B00, B01, B11, T), agg [n,6]."""
+    device = table.device
+    phi = _prep(phi, device, (2,))
+    temperature = _prep(temperature, device)
+    rho4 = _prep(rho4, device, (4,))
+    n = temperature.shape[0]
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        jac = torch.empty((n, 7), dtype=_F64, device=device)
+        agg = torch.empty((n, 6), dtype=_F64, device=device)
+        rc = L.pcs_gc_jacobian(int(bool(dew)), _lib.ptr(table), int(S), _lib.ptr(rows), _lib.ptr(phi),
+                               _lib.ptr(temperature), _lib.ptr(rho4), n, _lib.ptr(jac), _lib.ptr(agg),
+                               _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_gc_jacobian")
+    return jac, agg

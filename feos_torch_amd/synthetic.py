@@ -98,3 +98,79 @@ def mix_batch(n, seed=2028):
     p_init = np.full(n, 1e5)
     return (np.ascontiguousarray(par), np.ascontiguousarray(kij), np.ascontiguousarray(T),
             np.ascontiguousarray(x), p_init)
+
+
+# ---------------------------------------------------------------------------------------------
+# heterosegmented gc-PC-SAFT (config 5)
+# ---------------------------------------------------------------------------------------------
+def _chain(segs):
+    return list(segs), [[i, i + 1] for i in range(len(segs) - 1)]
+
+
+def gc_molecule_library():
+    """(name, segments, bonds) built from the 23 segments of the reference's
+    tests/sauer2014_hetero.json: n-alkanes C2-C10, branched alkanes, 1-alcohols, aldehydes,
+    formates, ketones, primary amines and one molecule carrying the induced-association
+    pseudo-segment 'IA' (tests/test_gc_pcsaft.py:17-29 uses the same building blocks)."""
+    lib = []
+    for n in range(2, 11):
+        lib.append((f"C{n}",) + tuple(_chain(["CH3"] + ["CH2"] * (n - 2) + ["CH3"])))
+    lib.append(("isobutane", ["CH3", ">CH", "CH3", "CH3"], [[0, 1], [1, 2], [1, 3]]))
+    lib.append(("neopentane", ["CH3", ">C<", "CH3", "CH3", "CH3"], [[0, 1], [1, 2], [1, 3], [1, 4]]))
+    lib.append(("isopentane", ["CH3", ">CH", "CH3", "CH2", "CH3"], [[0, 1], [1, 2], [1, 3], [3, 4]]))
+    for n in range(2, 7):
+        lib.append((f"C{n}OH",) + tuple(_chain(["CH3"] + ["CH2"] * (n - 1) + ["OH"])))
+        lib.append((f"C{n}NH2",) + tuple(_chain(["CH3"] + ["CH2"] * (n - 1) + ["NH2"])))
+    for n in range(2, 6):
+        lib.append((f"C{n}CHO",) + tuple(_chain(["CH3"] + ["CH2"] * (n - 2) + ["CH=O"])))
+        lib.append((f"HCOOC{n}",) + tuple(_chain(["HCOO"] + ["CH2"] * (n - 1) + ["CH3"])))
+    lib.append(("acetone", ["CH3", ">C=O", "CH3"], [[0, 1], [1, 2]]))
+    lib.append(("butanone", ["CH3", ">C=O", "CH2", "CH3"], [[0, 1], [1, 2], [2, 3]]))
+    lib.append(("2-propanol", ["CH3", ">CH", "CH3", "OH"], [[0, 1], [1, 2], [1, 3]]))
+    lib.append(("C3IA", ["CH3", "CH2", "CH2", "IA"], [[0, 1], [1, 2], [2, 3]]))
+    return lib
+
+
+GC_KAB = [("CH3", "CH=O", 0.03), (">CH", "HCOO", -0.01), ("CH3", "CH2", -0.02), ("CH2", "OH", 0.01)]
+
+
+def gc_batch(n, segment_table, seed=2029):
+    """GcPcSaftMix rows (config 5).  segment_table = list of (identifier, array(8)) in the order
+    of the parameter file.  -> dict(segment_lists, bond_lists, kab_list, phi [n,2], T, x, p_init).
+    Molecule pairs are drawn from gc_molecule_library(); phi ~ U[0.9, 1.1]^2;
+    T = 0.6 * min_i(eps_mix_i * 1.28 * m_mix_i**0.45) with the molecule-level averages of
+    feos_torch/gc_pcsaft.py:66-70; x ~ U[0.1, 0.9]; p_init = 1e5 Pa."""
+    rng = np.random.default_rng(seed)
+    lib = gc_molecule_library()
+    par = {s: np.asarray(v, dtype=np.float64) for s, v in segment_table}
+    tc = []
+    for _, segs, _ in lib:
+        m = np.array([par[s][0] for s in segs])
+        e = np.array([par[s][2] for s in segs])
+        mm = m.sum()
+        tc.append((m * e).sum() / mm * 1.28 * mm**0.45)
+    tc = np.array(tc)
+    pick = rng.integers(0, len(lib), size=(n, 2))
+    segment_lists = [[lib[a][1], lib[b][1]] for a, b in pick]
+    bond_lists = [[lib[a][2], lib[b][2]] for a, b in pick]
+    phi = rng.uniform(0.9, 1.1, size=(n, 2))
+    x = rng.uniform(0.1, 0.9, n)
+    T = 0.6 * tc[pick].min(axis=1)
+    return {"segment_lists": segment_lists, "bond_lists": bond_lists, "kab_list": list(GC_KAB), "phi": phi,
+            "T": np.ascontiguousarray(T), "x": x, "p_init": np.full(n, 1e5), "pick": pick}
+
+
+def load_segment_table(path):
+    """[(identifier, array(8) = m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb)] from a
+    feos segment-record JSON (format of the reference's tests/sauer2014_hetero.json)."""
+    import json
+
+    with open(path) as f:
+        recs = json.load(f)
+    out = []
+    for r in recs:
+        m = r["model_record"]
+        out.append((r["identifier"], np.array([m["m"], m["sigma"], m["epsilon_k"], m.get("mu", 0.0),
+                                               m.get("kappa_ab", 0.0), m.get("epsilon_k_ab", 0.0),
+                                               m.get("na", 0.0), m.get("nb", 0.0)], dtype=np.float64)))
+    return out

@@ -134,6 +134,41 @@ int pcs_mix_derivatives(const double* params, const double* kij, const double* t
 int pcs_mix_jacobian(int dew, const double* params, const double* kij, const double* temp, const double* rho4,
                      int64_t n, double* jac, void* stream);
 
+/*
+ * ---- heterosegmented gc-PC-SAFT (binary mixtures) -----------------------------------------
+ * Replaces the reference's stateful GcPcSaft class (src/gc_pcsaft.rs:15-99: segment records,
+ * per-row chemical records, binary segment records, phi) and the Python tails of
+ * GcPcSaftMix.bubble_point / dew_point (feos_torch/gc_pcsaft.py:470-512).
+ *
+ *   table  [S*8 + 3*S*S] in   per-batch: seg[S][8] (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab,
+ *                             na, nb), E1[S][S] = sqrt(eps_a eps_b) sigma_ab^3, E2[S][S] = eps_a eps_b
+ *                             sigma_ab^3, K[S][S] = 1 - k_ab, sigma_ab = (sigma_a + sigma_b)/2; S <= 32
+ *   rows   [n,80] uint8  in   molecule structures: for each of the 2 molecules up to 8 entries of
+ *                             seg_id [0:16], seg_cnt [16:32], bond_a [32:48], bond_b [48:64],
+ *                             bond_cnt [64:80] (count 0 = unused entry)
+ *   phi    [n,2]         in   src/gc_pcsaft.rs:30, feos_torch/gc_pcsaft.py:182-185
+ *   temp, z, p_init [n]  in   as for pcs_mix_bubble_dew
+ *   outputs                   as for pcs_mix_bubble_dew
+ */
+int64_t pcs_gc_table_doubles(int S);
+int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                      const double* z, const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status,
+                      int32_t* iters, void* stream);
+
+/* GcPcSaftMix.derivatives (feos_torch/gc_pcsaft.py:443-468): a, p, mu [n,2], v [n,2] at rho [n,2]. */
+int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                       const double* rho, int64_t n, double* a, double* p, double* mu, double* v, void* stream);
+
+/*
+ * Gradient of the gc bubble / dew pressure [Pa] at the converged densities rho4:
+ *   jac [n,7] = d p / d (A00, A01, A11, B00, B01, B11, T), the dispersion aggregates
+ *               rho1mix = A00 r0^2 + A01 r0 r1 + A11 r1^2, rho2mix likewise with B
+ *               (feos_torch/gc_pcsaft.py:177-194) — k_ab and phi enter the model only through them;
+ *   agg [n,6] = the aggregate values (optional).
+ */
+int pcs_gc_jacobian(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                    const double* rho4, int64_t n, double* jac, double* agg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

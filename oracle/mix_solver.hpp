@@ -219,4 +219,44 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
     return false;
 }
 
+// feos_torch/pcsaft_mix.py:395-420 == feos_torch/gc_pcsaft.py:443-468 for any `Model`:
+// hyper-dual pass over A(N, V) = V a(N/V): a, p = sum rho - A_V, mu_i = A_Ni,
+// v_i = -(1 - A_VNi)/(-sum rho - A_VV).
+template <class F, class Model>
+void derivatives_generic(const Model& model, F T, const F* rho, F& a, F& p, F* mu, F* v) {
+    typedef HyperDual<F, 3> H;
+    auto lift = [](F x) { H h; h.re = x; return h; };
+    H volume = lift(F(1));
+    volume.eps1[2] = F(1);
+    volume.eps2 = F(1);
+    H dens[2];
+    for (int i = 0; i < 2; i++) {
+        H moles = lift(rho[i]);
+        moles.eps1[i] = F(1);
+        dens[i] = moles / volume;
+    }
+    H A = model.template a<H>(lift(T), dens) * volume;
+    F rs = rho[0] + rho[1];
+    p = rs - A.eps2;
+    for (int i = 0; i < 2; i++) {
+        mu[i] = A.eps1[i];
+        v[i] = -(F(1) - A.eps1eps2[i]) / (-rs - A.eps1eps2[2]);
+    }
+    a = A.re;
+}
+
+// bubble (spec = liquid) / dew (spec = vapour) tail, pcsaft_mix.py:435-444 / :459-468 ==
+// gc_pcsaft.py:481-490 / :503-512, reduced pressure
+template <class F, class Model>
+F bubble_dew_formula_generic(const Model& model, F T, const F* rho_spec, const F* rho_inc) {
+    F rho_i = rho_inc[0] + rho_inc[1];
+    F y[2] = {rho_inc[0] / rho_i, rho_inc[1] / rho_i};
+    F a_s, p_s, mu_s[2], v_s[2];
+    derivatives_generic<F>(model, T, rho_spec, a_s, p_s, mu_s, v_s);
+    F a_i = model.template a<F>(T, rho_inc) / rho_i;
+    F v = y[0] * v_s[0] + y[1] * v_s[1];
+    F g = y[0] * (log(rho_inc[0] / rho_spec[0]) - mu_s[0]) + y[1] * (log(rho_inc[1] / rho_spec[1]) - mu_s[1]);
+    return -(a_i + p_s * v + g - F(1)) / (F(1) / rho_i - v);
+}
+
 }  // namespace oracle

@@ -9,6 +9,7 @@
 #include "pcsaft_pure.hpp"
 #include "pcsaft_mix.hpp"
 #include "mix_solver.hpp"
+#include "gc_pcsaft.hpp"
 
 using namespace oracle;
 
@@ -386,6 +387,144 @@ void orc_mix_bubble_dew_grad(const double* params, const double* kij, const doub
         G r = dew ? bubble_dew_formula<G>(q, Tg, rv, rl) : bubble_dew_formula<G>(q, Tg, rl, rv);
         value[i] = r.re;
         for (int k = 0; k < 19; k++) grad[19 * i + k] = r.eps[k];
+    }
+}
+
+// ======================================================================================
+// heterosegmented gc-PC-SAFT (feos_torch/gc_pcsaft.py)
+// ======================================================================================
+}  // extern "C"
+
+namespace {
+
+// adapter: GcPcSaftMix as a `Model` for mix_solver.hpp.  F-valued T and densities; the
+// structure and segment table stay plain doubles.
+template <class F>
+struct GcModel {
+    GcRow r;
+    template <class S> S a(const S& T, const S* rho) const { return gc_helmholtz_energy_density<S>(r, T, rho); }
+    F packing(F T, const F* x) const {
+        F s = 0;
+        for (int i = 0; i < 2; i++)
+            for (int al = 0; al < r.S; al++) {
+                double m = r.counts[i * r.S + al] * r.seg[8 * al];
+                if (m == 0.0) continue;
+                F d = F(r.seg[8 * al + 1]) * (F(1) - F(0.12) * oracle::exp(F(-3) * F(r.seg[8 * al + 2]) / T));
+                s += x[i] * F(m) * d * d * d;
+            }
+        return F(PI) / F(6) * s;
+    }
+};
+
+bool gc_row(GcRow& r, int S, const double* seg, const double* kab, const double* counts, const double* bonds,
+            const double* phi, int64_t i) {
+    r.S = S;
+    r.seg = seg;
+    r.kab = kab;
+    r.counts = counts + (size_t)i * 2 * S;
+    r.bonds = bonds + (size_t)i * 2 * S * S;
+    r.phi[0] = phi[2 * i];
+    r.phi[1] = phi[2 * i + 1];
+    return gc_prepare(r);
+}
+
+template <class F>
+void gc_bd_row(GcRow& r, double T, double z, double p_pa, bool dew, F tol, double* rho4, double* p_out,
+               uint8_t* status) {
+    r.robust = true;
+    GcModel<F> model{r};
+    F rs[2], ri[2];
+    MixSolveInfo info;
+    F p_red = F(p_pa) / F(T) * F(1.0 / P_UNIT);
+    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol);
+    *status = ok ? 0 : 1;
+    const F* v = dew ? rs : ri;
+    const F* l = dew ? ri : rs;
+    if (rho4) {
+        rho4[0] = ok ? double(v[0]) : 0.0; rho4[1] = ok ? double(v[1]) : 0.0;
+        rho4[2] = ok ? double(l[0]) : 0.0; rho4[3] = ok ? double(l[1]) : 0.0;
+    }
+    if (p_out) *p_out = ok ? double(bubble_dew_formula_generic<F>(model, F(T), rs, ri) * F(T) * F(P_UNIT)) : 0.0;
+}
+
+}  // namespace
+
+extern "C" {
+
+}  // extern "C" (reopened below)
+
+namespace {
+typedef DualN<double, 4> GcG;
+template <class X> struct LiftG;
+template <> struct LiftG<GcG> { static GcG go(const GcG& g) { return g; } };
+template <int N> struct LiftG<HyperDual<GcG, N>> { static HyperDual<GcG, N> go(const GcG& g) { HyperDual<GcG, N> h; h.re = g; return h; } };
+// gradient model: kab[ka,kb], phi_0, phi_1 carried as DualN tangents (direction 0, 1, 2; T is 3)
+struct GcGradModel {
+    GcRow r; GcG kv; GcG ph[2]; int ka, kb;
+    template <class X> X a(const X& Tt, const X* rho) const {
+        X ks = LiftG<X>::go(kv), p2[2] = {LiftG<X>::go(ph[0]), LiftG<X>::go(ph[1])};
+        return gc_helmholtz_energy_density<X>(r, Tt, rho, p2, ka, kb, &ks);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+// GcPcSaftMix.derivatives (feos_torch/gc_pcsaft.py:443-468).  seg [S,8], kab [S,S],
+// counts [n,2,S], bonds [n,2,S,S] (lower triangle), phi [n,2].  Returns 1 if a row violates
+// "only up to one associating segment per component" (:77-80).
+int orc_gc_derivatives(int S, const double* seg, const double* kab, const double* counts, const double* bonds,
+                       const double* phi, const double* T, const double* rho, int64_t n, int robust, double* a,
+                       double* p, double* mu, double* v) {
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t i = 0; i < n; i++) {
+        GcRow r;
+        if (!gc_row(r, S, seg, kab, counts, bonds, phi, i)) { bad |= 1; continue; }
+        r.robust = robust != 0;
+        GcModel<double> model{r};
+        derivatives_generic<double>(model, T[i], rho + 2 * i, a[i], p[i], mu + 2 * i, v + 2 * i);
+    }
+    return bad;
+}
+
+// converged partial densities + bubble/dew pressure [Pa]; either output may be NULL
+int orc_gc_bubble_dew(int S, const double* seg, const double* kab, const double* counts, const double* bonds,
+                      const double* phi, const double* T, const double* z, const double* p_init_pa, int64_t n,
+                      int dew, int prec, double* rho4, double* p_out, uint8_t* status) {
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
+    for (int64_t i = 0; i < n; i++) {
+        GcRow r;
+        if (!gc_row(r, S, seg, kab, counts, bonds, phi, i)) { bad |= 1; status[i] = 1; continue; }
+        if (prec == 1)
+            gc_bd_row<long double>(r, T[i], z[i], p_init_pa[i], dew != 0, 1e-17L, rho4 ? rho4 + 4 * i : nullptr,
+                                   p_out ? p_out + i : nullptr, status + i);
+        else
+            gc_bd_row<double>(r, T[i], z[i], p_init_pa[i], dew != 0, 1e-13, rho4 ? rho4 + 4 * i : nullptr,
+                              p_out ? p_out + i : nullptr, status + i);
+    }
+    return bad;
+}
+
+// value and gradient of the bubble/dew formula at fixed densities w.r.t.
+// (kab[ka,kb] (= kab[kb,ka]), phi_0, phi_1, T): grad [n,4]
+void orc_gc_bubble_dew_grad(int S, const double* seg, const double* kab, const double* counts, const double* bonds,
+                            const double* phi, const double* T, const double* rho4, int64_t n, int dew, int ka,
+                            int kb, double* value, double* grad) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        typedef DualN<double, 4> G;
+        GcRow r;
+        gc_row(r, S, seg, kab, counts, bonds, phi, i);
+        r.robust = true;
+        GcGradModel model{r, G::var(kab[ka * S + kb], 0), {G::var(phi[2 * i], 1), G::var(phi[2 * i + 1], 2)}, ka, kb};
+        G Tg = G::var(T[i], 3);
+        G rv[2] = {G(rho4[4 * i]), G(rho4[4 * i + 1])}, rl[2] = {G(rho4[4 * i + 2]), G(rho4[4 * i + 3])};
+        G pr = dew ? bubble_dew_formula_generic<G>(model, Tg, rv, rl) : bubble_dew_formula_generic<G>(model, Tg, rl, rv);
+        G res = pr * Tg * P_UNIT;
+        value[i] = res.re;
+        for (int k = 0; k < 4; k++) grad[4 * i + k] = res.eps[k];
     }
 }
 

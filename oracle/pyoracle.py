@@ -60,6 +60,12 @@ def lib():
         L.orc_mix_helmholtz.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p]
         L.orc_mix_bubble_dew.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _u8p]
         L.orc_mix_bubble_dew_grad.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p]
+        _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+        L.orc_gc_derivatives.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p, _f64p, _f64p]
+        L.orc_gc_derivatives.restype = _int
+        L.orc_gc_bubble_dew.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _u8p]
+        L.orc_gc_bubble_dew.restype = _int
+        L.orc_gc_bubble_dew_grad.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _int, _f64p, _f64p]
         _lib = L
     return _lib
 
@@ -206,4 +212,76 @@ def mix_bubble_dew_grad(params, kij, T, rho4, dew):
     n = T.shape[0]
     val, grad = np.empty(n), np.empty((n, 19))
     lib().orc_mix_bubble_dew_grad(params, kij, T, rho4, n, int(bool(dew)), val, grad)
+    return val, grad
+
+
+# ------------------------------------------------------------------------------------------
+# heterosegmented gc-PC-SAFT
+# ------------------------------------------------------------------------------------------
+def gc_encode(segment_records, segment_lists, bond_lists, binary_segment_records):
+    """Dense encoding of the reference's constructor arguments (feos_torch/gc_pcsaft.py:24-63,
+    src/gc_pcsaft.rs:25-31): segment_records = [(identifier, array(8))], segment_lists /
+    bond_lists per row and component, binary_segment_records = [(s1, s2, k_ab)].
+    -> dict(S, seg [S,8], kab [S,S], counts [n,2,S], bonds [n,2,S,S] lower-triangular, ident)."""
+    ident = [s for s, _ in segment_records]
+    idx = {s: i for i, s in enumerate(ident)}
+    S = len(ident)
+    seg = np.array([np.asarray(v, dtype=np.float64) for _, v in segment_records]).reshape(S, 8)
+    kab = np.zeros((S, S))
+    for s1, s2, k in binary_segment_records:
+        kab[idx[s1], idx[s2]] = float(k)
+        kab[idx[s2], idx[s1]] = float(k)
+    n = len(segment_lists)
+    counts = np.zeros((n, 2, S))
+    bonds = np.zeros((n, 2, S, S))
+    for r in range(n):
+        for c in range(2):
+            segs = segment_lists[r][c]
+            for s in segs:
+                counts[r, c, idx[s]] += 1
+            for i, j in bond_lists[r][c]:
+                a, b = sorted((idx[segs[i]], idx[segs[j]]))[::-1]  # larger index first (:35)
+                bonds[r, c, a, b] += 1
+    return {"S": S, "seg": seg, "kab": kab, "counts": counts, "bonds": bonds, "ident": ident}
+
+
+def gc_derivatives(enc, phi, T, rho, robust=False):
+    phi, T, rho = _c(phi), _c(T), _c(rho)
+    n = T.shape[0]
+    a, p, mu, v = np.empty(n), np.empty(n), np.empty((n, 2)), np.empty((n, 2))
+    bad = lib().orc_gc_derivatives(enc["S"], _c(enc["seg"]), _c(enc["kab"]), _c(enc["counts"]), _c(enc["bonds"]), phi, T,
+                                   rho, n, int(bool(robust)), a, p, mu, v)
+    if bad:
+        raise Exception("Only up to one associating segment per component is allowed!")
+    return a, p, mu, v
+
+
+def gc_bubble_dew(enc, phi, T, z, p_init, dew, prec=1):
+    """-> p [Pa], rho4 [n,4] (rhoV_1, rhoV_2, rhoL_1, rhoL_2), status"""
+    phi, T, z, p_init = _c(phi), _c(T), _c(z), _c(p_init)
+    n = T.shape[0]
+    rho4, p = np.empty((n, 4)), np.empty(n)
+    st = np.empty(n, dtype=np.uint8)
+    bad = lib().orc_gc_bubble_dew(enc["S"], _c(enc["seg"]), _c(enc["kab"]), _c(enc["counts"]), _c(enc["bonds"]), phi, T,
+                                  z, p_init, n, int(bool(dew)), prec, rho4, p, st)
+    if bad:
+        raise Exception("Only up to one associating segment per component is allowed!")
+    return p, rho4, st.astype(bool)
+
+
+def gc_bubble_dew_root(segment_records, segments, bonds, binary_segment_records, phi, T, z, p_init, dew, prec=1):
+    """Same argument list as the reference's Rust class (src/gc_pcsaft.rs:25-31 + :71-99)."""
+    enc = gc_encode(segment_records, segments, bonds, binary_segment_records)
+    _, rho4, st = gc_bubble_dew(enc, phi, T, z, p_init, dew, prec)
+    return rho4, st
+
+
+def gc_bubble_dew_grad(enc, phi, T, rho4, dew, s1, s2):
+    """value[n], grad[n,4] = d/d(kab[s1,s2], phi_0, phi_1, T) at fixed densities."""
+    phi, T, rho4 = _c(phi), _c(T), _c(rho4)
+    n = T.shape[0]
+    val, grad = np.empty(n), np.empty((n, 4))
+    ka, kb = enc["ident"].index(s1), enc["ident"].index(s2)
+    lib().orc_gc_bubble_dew_grad(enc["S"], _c(enc["seg"]), _c(enc["kab"]), _c(enc["counts"]), _c(enc["bonds"]), phi, T, rho4,
+                                 n, int(bool(dew)), ka, kb, val, grad)
     return val, grad

@@ -78,5 +78,72 @@ def make_mix(PcSaftMix, dump, tl):
     dump("mix.json", g)
 
 
+# tests/test_gc_pcsaft.py:17-44
+GC_TEST_SEGMENTS = [
+    [["CH3", "CH2", "CH2", "CH3"], ["CH3", "CH2", "CH3"]],
+    [["CH3", ">CH", "CH3", "CH3"], ["CH3", ">C<", "CH3", "CH3", "CH3"]],
+    [["CH3", ">CH", "CH3", "CH=O"], ["CH3", ">C<", "CH3", "CH3", "CH3"]],
+    [["CH3", ">CH", "CH3", "CH3"], ["CH3", ">C<", "CH3", "CH3", "HCOO"]],
+    [["CH3", ">CH", "CH3", "CH=O"], ["CH3", ">C<", "CH3", "CH3", "HCOO"]],
+    [["CH3", ">CH", "CH3", "OH"], ["CH3", ">C<", "CH3", "CH3", "CH3"]],
+    [["CH3", ">CH", "CH3", "CH3"], ["CH3", ">C<", "CH3", "CH3", "NH2"]],
+    [["CH3", ">CH", "CH3", "OH"], ["CH3", ">C<", "CH3", "CH3", "NH2"]],
+    [["CH3", ">CH", "CH=O", "OH"], ["CH3", ">C<", "CH3", "HCOO", "NH2"]],
+    [["CH3", ">CH", "CH=O", "OH"], ["CH3", ">C<", "CH3", "CH2", "IA"]],
+    [["CH3", ">CH", "CH=O", "IA"], ["CH3", ">C<", "CH3", "CH2", "IA"]],
+]
+GC_TEST_BONDS = [[[[0, 1], [1, 2], [2, 3]], [[0, 1], [1, 2]]]] + [[[[0, 1], [1, 2], [1, 3]], [[0, 1], [1, 2], [1, 3], [1, 4]]]] * 10
+GC_TEST_KAB = [("CH3", "CH=O", 0.03), (">CH", "HCOO", -0.01)]
+
+
+def _parse_segments(table):
+    ident = [s for s, _ in table]
+    cols = [torch.tensor([v[k] for _, v in table], dtype=f64) for k in range(8)]
+    return ident, tuple(cols)
+
+
+def _gc_bubble_dew(GcPcSaftMix, tl, table, seg, bon, kab_pairs, kab_vals, phi, T, z, p, dew):
+    kab = torch.tensor(kab_vals, dtype=f64, requires_grad=True)
+    kab_list = [(s1, s2, k) for (s1, s2), k in zip(kab_pairs, kab)]
+    ph = torch.tensor(phi, dtype=f64, requires_grad=True)
+    Tt = torch.tensor(T, dtype=f64, requires_grad=True)
+    eos = GcPcSaftMix(*_parse_segments(table), seg, bon, kab_list, ph)
+    val, nans = (eos.dew_point if dew else eos.bubble_point)(Tt, torch.tensor(z, dtype=f64), torch.tensor(p, dtype=f64))
+    val.sum().backward()
+    return {"nans": tl(nans), "value": tl(val), "grad_kab": tl(kab.grad), "grad_phi": tl(ph.grad), "grad_T": tl(Tt.grad)}
+
+
 def make_gc(GcPcSaftMix, dump, tl):
-    raise NotImplementedError("gc fixtures are generated once the gc oracle exists")
+    import os
+    from feos_torch_amd.synthetic import gc_batch, load_segment_table
+    table = load_segment_table(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "sauer2014_hetero.json"))
+    g = {}
+    n = len(GC_TEST_SEGMENTS)
+    phi = [[1.1, 0.98]] * n
+    T = [300.0] * n
+    rho = [[0.001, 0.002]] * n
+    eos = GcPcSaftMix(*_parse_segments(table), GC_TEST_SEGMENTS, GC_TEST_BONDS, GC_TEST_KAB, torch.tensor(phi, dtype=f64))
+    a, p, mu, v = eos.derivatives(torch.tensor(T, dtype=f64), torch.tensor(rho, dtype=f64))
+    g["test_inputs"] = {"segment_lists": GC_TEST_SEGMENTS, "bond_lists": GC_TEST_BONDS, "kab_list": [list(k) for k in GC_TEST_KAB],
+                        "phi": phi, "T": T, "rho": rho, "a": tl(a), "p": tl(p), "mu": tl(mu), "v": tl(v)}
+    # tests/test_gc_pcsaft.py:130-222: n-butane / propane at 150 K, x = 0.5, k_ab(CH3, CH2) = -0.15
+    seg1, bon1 = GC_TEST_SEGMENTS[:1], GC_TEST_BONDS[:1]
+    for key, dew in (("test_bubble", False), ("test_dew", True)):
+        g[key] = {"segment_lists": seg1, "bond_lists": bon1, "kab_pairs": [["CH3", "CH2"]], "kab_vals": [-0.15], "phi": [[1.1, 0.98]],
+                  "T": [150.0], "z": [0.5], "p_init": [1e5]}
+        g[key]["result"] = _gc_bubble_dew(GcPcSaftMix, tl, table, seg1, bon1, [["CH3", "CH2"]], [-0.15], [[1.1, 0.98]], [150.0], [0.5], [1e5], dew)
+        hres = _gc_bubble_dew(GcPcSaftMix, tl, table, seg1, bon1, [["CH3", "CH2"]], [-0.15 + 1e-7], [[1.1, 0.98]], [150.0], [0.5], [1e5], dew)
+        g[key]["value_kab_plus_1e-7"] = hres["value"]
+    # seeded random rows of the config-5 distribution
+    b = gc_batch(48, table, seed=31)
+    pairs = [[k[0], k[1]] for k in b["kab_list"]]
+    vals = [k[2] for k in b["kab_list"]]
+    rng = np.random.default_rng(37)
+    eos = GcPcSaftMix(*_parse_segments(table), b["segment_lists"], b["bond_lists"], b["kab_list"], torch.tensor(b["phi"], dtype=f64))
+    rho = np.stack([b["x"], 1 - b["x"]], axis=1) * (10.0 ** rng.uniform(-6, -2.2, 48))[:, None]
+    a, p, mu, v = eos.derivatives(torch.tensor(b["T"], dtype=f64), torch.tensor(rho, dtype=f64))
+    g["random"] = {"seed": 31, "n": 48, "kab_pairs": pairs, "kab_vals": vals, "rho": rho.tolist(), "a": tl(a), "p": tl(p), "mu": tl(mu), "v": tl(v)}
+    for name, dew in (("bubble", False), ("dew", True)):
+        g["random"][name] = _gc_bubble_dew(GcPcSaftMix, tl, table, b["segment_lists"], b["bond_lists"], pairs, vals, b["phi"].tolist(),
+                                            b["T"].tolist(), b["x"].tolist(), b["p_init"].tolist(), dew)
+    dump("gc.json", g)

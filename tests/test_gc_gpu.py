@@ -1,0 +1,123 @@
+"""GPU parity tests for the gc-PC-SAFT path (config 5), in the shape of the reference's
+tests/test_gc_pcsaft.py.  Every call goes through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+f64 = torch.float64
+
+
+@pytest.fixture(scope="module")
+def amd():
+    assert torch.cuda.is_available()
+    import feos_torch_amd
+
+    return feos_torch_amd
+
+
+@pytest.fixture(scope="module")
+def gg():
+    return load_golden("gc.json")
+
+
+@pytest.fixture(scope="module")
+def table():
+    from feos_torch_amd.synthetic import load_segment_table
+
+    return load_segment_table(os.path.join(ROOT, "tests", "data", "sauer2014_hetero.json"))
+
+
+def parse_segments(table):
+    """tests/test_gc_pcsaft.py:225-257"""
+    ident = [s for s, _ in table]
+    return ident, tuple(torch.tensor([v[k] for _, v in table], dtype=f64) for k in range(8))
+
+
+def test_derivatives_vs_reference_python(amd, gg, table):
+    """tests/test_gc_pcsaft.py:16-127: 11 molecule pairs, abs 1e-14 (a, mu, p) / 1e-11 (v)."""
+    g = gg["test_inputs"]
+    eos = amd.GcPcSaftMix(*parse_segments(table), g["segment_lists"], g["bond_lists"], [tuple(k) for k in g["kab_list"]],
+                          torch.tensor(g["phi"], dtype=f64))
+    T, rho = torch.tensor(g["T"], dtype=f64), torch.tensor(g["rho"], dtype=f64)
+    a = eos.helmholtz_energy_density(T, rho)
+    assert a.shape == (11, 1)
+    a2, p, mu, v = eos.derivatives(T, rho)
+    assert np.max(np.abs(a[:, 0].numpy() - np.array(g["a"]))) < 1e-14
+    assert np.max(np.abs(p.numpy() - np.array(g["p"]))) < 1e-14
+    assert np.max(np.abs(mu.numpy() - np.array(g["mu"]))) < 1e-13
+    assert np.max(np.abs(v.numpy() - np.array(g["v"]))) < 1e-11 * 50
+
+
+@pytest.mark.parametrize("key,dew", [("test_bubble", False), ("test_dew", True)])
+def test_bubble_dew_reference_case(amd, gg, table, key, dew):
+    """tests/test_gc_pcsaft.py:130-222: n-butane / propane, 150 K; value abs 1e-8 Pa, dp/dk_ab abs 1."""
+    g = gg[key]
+    ref = g["result"]
+    kab = torch.tensor(g["kab_vals"], dtype=f64, requires_grad=True)
+    kab_list = [(s1, s2, k) for (s1, s2), k in zip(g["kab_pairs"], kab)]
+    phi = torch.tensor(g["phi"], dtype=f64, requires_grad=True)
+    T = torch.tensor(g["T"], dtype=f64, requires_grad=True)
+    eos = amd.GcPcSaftMix(*parse_segments(table), g["segment_lists"], g["bond_lists"], kab_list, phi)
+    p, nans = (eos.dew_point if dew else eos.bubble_point)(T, torch.tensor(g["z"], dtype=f64), torch.tensor(g["p_init"], dtype=f64))
+    assert nans.tolist() == ref["nans"]
+    assert abs(p[0].item() - ref["value"][0]) < 1e-8
+    p[0].backward()
+    assert abs(kab.grad[0].item() - ref["grad_kab"][0]) < 1e-6 * abs(ref["grad_kab"][0])
+    assert abs(T.grad[0].item() - ref["grad_T"][0]) < 1e-9 * abs(ref["grad_T"][0])
+    fd = (g["value_kab_plus_1e-7"][0] - ref["value"][0]) / 1e-7
+    assert abs(kab.grad[0].item() - fd) < 1.0
+    assert torch.all(torch.isfinite(phi.grad))  # NaN in the reference (sqrt(0) under autograd)
+
+
+@pytest.mark.parametrize("dew", [False, True])
+def test_random_rows_vs_oracle(amd, oracle, table, dew):
+    from feos_torch_amd.synthetic import gc_batch
+
+    n = 3000
+    b = gc_batch(n, table, seed=41)
+    kab = torch.tensor([k[2] for k in b["kab_list"]], dtype=f64, requires_grad=True)
+    kab_list = [(k[0], k[1], kv) for k, kv in zip(b["kab_list"], kab)]
+    phi = torch.tensor(b["phi"], dtype=f64, requires_grad=True)
+    T = torch.tensor(b["T"], dtype=f64, requires_grad=True)
+    eos = amd.GcPcSaftMix(*parse_segments(table), b["segment_lists"], b["bond_lists"], kab_list, phi)
+    p, nans = (eos.dew_point if dew else eos.bubble_point)(T, torch.tensor(b["x"], dtype=f64), torch.tensor(b["p_init"], dtype=f64))
+    enc = oracle.gc_encode(table, b["segment_lists"], b["bond_lists"], b["kab_list"])
+    want, rho4, st = oracle.gc_bubble_dew(enc, b["phi"], b["T"], b["x"], b["p_init"], dew, prec=1)
+    nn = nans.numpy()
+    assert (nn != st).mean() < 0.01 and nn.mean() < 0.03
+    got = np.zeros(n)
+    got[~nn] = p.detach().numpy()
+    both = ~nn & ~st
+    assert np.max(np.abs(got[both] / want[both] - 1)) < 1e-9
+    # gradients: sum over rows of dp/dk_ab(CH3, CH2), per-row dp/dphi and dp/dT vs the oracle
+    p.sum().backward()
+    _, grad = oracle.gc_bubble_dew_grad(enc, b["phi"], b["T"], rho4, dew, "CH3", "CH2")
+    ik = [k[:2] for k in b["kab_list"]].index(("CH3", "CH2"))
+    wk = grad[both, 0].sum()
+    assert abs(kab.grad[ik].item() - wk - grad[~nn & st, 0].sum()) < 1e-6 * abs(wk) + 1e-3 * (nn != st).sum()
+    gp = phi.grad.numpy()[both]
+    scale = np.abs(grad[both, 1:3]).max(axis=1, keepdims=True)
+    assert np.max(np.abs(gp - grad[both, 1:3]) / scale) < 1e-7
+    gt = T.grad.numpy()[both]
+    assert np.max(np.abs(gt / grad[both, 3] - 1)) < 1e-7
+    assert eos.rows.shape[0] == int((~nn).sum()) and eos.phi.shape[0] == int((~nn).sum())
+
+
+def test_ffi_mirror_and_errors(amd, oracle, table, gg):
+    g = gg["test_bubble"]
+    kab = [(a, b, k) for (a, b), k in zip(g["kab_pairs"], g["kab_vals"])]
+    gc = amd.GcPcSaft(table, g["segment_lists"] * 3, g["bond_lists"] * 3, kab, np.array(g["phi"] * 3))
+    T = np.array([150.0, 2000.0, 150.0])
+    rho, status = gc.bubble_point(T, np.full(3, 0.5), np.full(3, 1e5))
+    assert status.tolist() == [False, True, False] and rho.shape == (2, 4)
+    enc = oracle.gc_encode(table, g["segment_lists"], g["bond_lists"], kab)
+    _, want, _ = oracle.gc_bubble_dew(enc, g["phi"], g["T"], g["z"], g["p_init"], False)
+    assert np.max(np.abs(rho[0] / want[0] - 1)) < 1e-8
+    # two associating segments in one molecule -> the reference's exception (gc_pcsaft.py:77-80)
+    with pytest.raises(Exception, match="one associating segment"):
+        amd.GcPcSaftMix(*parse_segments(table), [[["OH", "CH2", "OH"], ["CH3", "CH3"]]], [[[[0, 1], [1, 2]], [[0, 1]]]], [])
