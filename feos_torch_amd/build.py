@@ -5,8 +5,16 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpcsaft_hip.so")
-SOURCES = ["pure_kernels.hip", "mix_kernels.hip", "gc_kernels.hip"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"]
+SOURCES = ["pure_kernels.hip", "pure_robust.hip", "mix_kernels.hip", "gc_kernels.hip"]
+# -fno-honor-nans/-infinities/-signed-zeros: lets the compiler fold the structural zeros of the dual
+# numbers (0 * x, x + 0); every NaN/inf test in the kernels is a bit test (is_finite_bits), so the
+# failure detection does not depend on IEEE comparison semantics.  Measured on k_pure_vle: x1.065,
+# x1.158 together with the v_rcp_f64 + Newton reciprocal (scratch A/B, 1e7 rows, MI355X).
+# They are applied to the pure-component translation unit only (the headline kernel); the
+# mixture / gc solvers keep strict IEEE comparisons.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+RELAXED = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros", "-DPCS_FAST_RCP"]
+RELAXED_SOURCES = {"pure_kernels.hip"}
 
 
 def _stale():
@@ -21,10 +29,23 @@ def _stale():
 def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT
-    cmd = ["hipcc"] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    # one hipcc per translation unit in parallel, then link
+    objs, procs = [], []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for s in SOURCES:
+        obj = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        cmd = ["hipcc"] + FLAGS + (RELAXED if s in RELAXED_SOURCES else []) + ["-c", "-o", obj, os.path.join(CSRC, s)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd))
+        objs.append(obj)
+    for p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, "hipcc")
+    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return OUT
 
 

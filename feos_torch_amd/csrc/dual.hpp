@@ -22,7 +22,26 @@ PCS_DEV double d_exp(double x) { return exp(x); }
 PCS_DEV double d_log(double x) { return log(x); }
 PCS_DEV double d_sqrt(double x) { return sqrt(x); }
 PCS_DEV double d_cbrt(double x) { return cbrt(x); }
+// fp64 reciprocal.  IEEE 1.0/x lowers to v_div_scale x2 + v_rcp_f64 + 5 FMA + v_div_fmas +
+// v_div_fixup (~11 VALU); the kernels only ever divide well-scaled finite numbers, so the
+// hardware estimate refined by two Newton steps (5 VALU, <= 1 ulp, measured 1.1e-16 over 1e-300..1e300)
+// is used where PCS_FAST_RCP is defined: the pure-component translation unit (build.py).  It maps
+// 0 and denormals to NaN instead of +-inf, which changes the path the mixture / gc solvers take
+// through degenerate pure-component limits, so those units keep the IEEE division.
+#ifdef PCS_FAST_RCP
+PCS_DEV double d_recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+#else
 PCS_DEV double d_recip(double x) { return 1.0 / x; }
+#endif
+// NaN / inf test that survives -fno-honor-nans style flags (pure bit test)
+PCS_DEV bool is_finite_bits(double x) {
+    return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
+}
 
 // =========================================================================================
 // D2<T>
@@ -111,7 +130,12 @@ template <class T, int N> PCS_DEV DN<T, N> operator-(const DN<T, N>& a, double b
 template <class T, int N> PCS_DEV DN<T, N> operator-(double b, const DN<T, N>& a) { DN<T, N> r; r.v = b - a.v; PCS_DN_LOOP r.e[i] = -a.e[i]; return r; }
 template <class T, int N> PCS_DEV DN<T, N> operator*(const DN<T, N>& a, double b) { DN<T, N> r; r.v = a.v * b; PCS_DN_LOOP r.e[i] = a.e[i] * b; return r; }
 template <class T, int N> PCS_DEV DN<T, N> operator*(double b, const DN<T, N>& a) { return a * b; }
-template <class T, int N> PCS_DEV DN<T, N> d_recip(const DN<T, N>& a) { T r = d_recip(a.v); return a.chain(r, -(r * r)); }
+// Parameter-tangent duals use the IEEE division: the fast reciprocal (<= 1 ulp) perturbs the
+// implicit-differentiation Newton updates of the induced-association site fraction enough to
+// shift dp/dT by ~1e-5 on those rows (measured, tests/test_gc_gpu.py); the gradient kernels are
+// not on the headline path, so exactness wins here.
+template <int N> PCS_DEV DN<double, N> d_recip(const DN<double, N>& a) { double r = 1.0 / a.v; return a.chain(r, -(r * r)); }
+template <class T, int N, PCS_IFDUAL(T)> PCS_DEV DN<T, N> d_recip(const DN<T, N>& a) { T r = d_recip(a.v); return a.chain(r, -(r * r)); }
 template <class T, int N> PCS_DEV DN<T, N> operator/(const DN<T, N>& a, const DN<T, N>& b) { return a * d_recip(b); }
 template <class T, int N> PCS_DEV DN<T, N> operator/(const DN<T, N>& a, double b) { double r = 1.0 / b; return a * r; }
 template <class T, int N> PCS_DEV DN<T, N> operator/(double b, const DN<T, N>& a) { return d_recip(a) * b; }

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* 
             double dp = (dew ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
             double val = dp * T * P_UNIT;
             if (d0 + j == 6) val += p_red * P_UNIT;
-            if (!ok) val = __builtin_nan("");
+            if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
 #pragma unroll
             for (int d = 0; d < GC_DIRS; d++)
                 if (d == d0 + j) g[d] = val;

@@ -95,7 +95,7 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
             double dp = (spec_is_vapor ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
             double val = dp * T * P_UNIT;
             if (d0 + j == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
-            if (!ok) val = __builtin_nan("");
+            if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
 #pragma unroll
             for (int d = 0; d < MIX_DIRS; d++)
                 if (d == d0 + j) g[d] = val;

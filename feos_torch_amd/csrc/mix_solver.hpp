@@ -63,10 +63,10 @@ PCS_DEV bool liquid_root(const Model& m, double x0, double x1, double p_spec, do
             rho = 0.62 / pk;
             line_eval(m, x0, x1, rho, p, dp, a);
         }
-        if (!(dp > 0.0) || !(p == p)) return false;
+        if (!(dp > 0.0) || !is_finite_bits(p)) return false;
         double step = (p - p_spec) / dp;
         double rho_new = rho - step;
-        if (!(rho_new > 0.0)) return false;
+        if (!(rho_new > 0.0) || !is_finite_bits(rho_new)) return false;
         double err = fabs(step) / rho;
         bool done = err <= 1e-10 || (it >= 3 && err < 1e-7 && err >= 0.25 * err_prev);
         err_prev = err;
@@ -196,7 +196,7 @@ PCS_DEV bool bubble_dew_solve(const Model& m, double z0, double p_init, MixResul
         double du[3];
         if (!solve3(A, du)) return false;
         double mx = fmax(fabs(du[0]), fmax(fabs(du[1]), fabs(du[2])));
-        if (!(mx == mx)) return false;
+        if (!is_finite_bits(mx)) return false;
         double scale = mx > 1.0 ? 1.0 / mx : 1.0;  // at most a factor e per iteration
         rs *= exp(scale * du[0]);
         ri0 *= exp(scale * du[1]);
@@ -213,7 +213,7 @@ PCS_DEV bool bubble_dew_solve(const Model& m, double z0, double p_init, MixResul
             PhaseEval nf = phase_eval(m, ri0, ri1);
             out.spec0 = sf.r0; out.spec1 = sf.r1; out.inc0 = ri0; out.inc1 = ri1;
             out.p = bubble_dew_formula(sf, nf);
-            return out.p == out.p;
+            return is_finite_bits(out.p);
         }
     }
     return false;

@@ -17,6 +17,13 @@
 #include "pure_solver.hpp"
 #include "pure_jacobian.hpp"
 
+// stage 2 (k_pure_vle_robust) lives in pure_robust.hip, compiled with strict IEEE semantics
+namespace pcs_abi {
+int launch_pure_vle_retry(const double* params, const double* temp, double* p_sat, double* rho_eq, double* rho_vl,
+                          uint8_t* status, int32_t* iters, const int32_t* retry, hipStream_t s);
+}
+#define launch_vle_retry pcs_abi::launch_pure_vle_retry
+
 using namespace pcs;
 using namespace pcs_abi;
 
@@ -25,7 +32,6 @@ thread_local char pcs_abi::g_err[256] = "";
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int RETRY_GRID = 1024;  // 64-thread workgroups of the robust pass
 constexpr int ROW_PAD = 9;  // doubles per staged row (8 + 1 pad): bank-conflict-free per-lane reads
 
 // Cooperative, coalesced load of the workgroup's parameter rows into LDS, then one row per lane.
@@ -86,46 +92,6 @@ __global__ __launch_bounds__(BLOCK) void k_pure_vle(const double* __restrict__ p
         status[i] = 1;  // provisional; the robust pass overwrites it
         int slot = atomicAdd(&retry[0], 1);
         retry[1 + slot] = (int32_t)i;  // n < 2^31 checked on the host
-    }
-}
-
-// K1b: robust pass over the compacted retry list (grid-stride, count read on device: no host sync).
-__global__ __launch_bounds__(64) void k_pure_vle_robust(const double* __restrict__ params,
-                                                        const double* __restrict__ temp,
-                                                        double* __restrict__ p_sat, double* __restrict__ rho_eq,
-                                                        double* __restrict__ rho_vl, uint8_t* __restrict__ status,
-                                                        int32_t* __restrict__ iters,
-                                                        const int32_t* __restrict__ retry) {
-    const int count = retry[0];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-        const int64_t i = retry[1 + k];
-        double par[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) par[j] = params[8 * i + j];
-        const double T = temp[i];
-        PureCoef<double> c;
-        pure_coef<double>(c, par, T, false);
-        VleResult r;
-        int st = vle_robust(c, r);
-        if (st == ST_OK) {
-            if (p_sat) p_sat[i] = r.p_star * T * P_UNIT;
-            if (rho_eq) rho_eq[i] = r.rho_l * (1.0 / RHO_UNIT);
-            if (rho_vl) {
-                rho_vl[2 * i] = r.rho_v;
-                rho_vl[2 * i + 1] = r.rho_l;
-            }
-            if (iters) iters[i] = 1000 + r.iters;
-            status[i] = 0;
-        } else {
-            if (p_sat) p_sat[i] = 0.0;
-            if (rho_eq) rho_eq[i] = 0.0;
-            if (rho_vl) {
-                rho_vl[2 * i] = 0.0;
-                rho_vl[2 * i + 1] = 0.0;
-            }
-            if (iters) iters[i] = -1;
-            status[i] = 1;
-        }
     }
 }
 
@@ -234,16 +200,6 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
                        iters, retry);
     e = hipGetLastError();
     if (e != hipSuccess) return fail("k_pure_vle launch", e);
-    return 0;
-}
-
-// stage 2: robust pass, small fixed grid; the retry count is read on the device (no host sync)
-static int launch_vle_retry(const double* params, const double* temp, double* p_sat, double* rho_eq,
-                            double* rho_vl, uint8_t* status, int32_t* iters, const int32_t* retry, hipStream_t s) {
-    hipLaunchKernelGGL(k_pure_vle_robust, dim3(RETRY_GRID), dim3(64), 0, s, params, temp, p_sat, rho_eq, rho_vl,
-                       status, iters, retry);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail("k_pure_vle_robust launch", e);
     return 0;
 }
 

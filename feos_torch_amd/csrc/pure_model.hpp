@@ -98,6 +98,25 @@ PCS_DEV R horner(const P* coef, const R& x) {
     return acc;
 }
 
+// Horner for the solver's R = D2<double> when x.d2 == 0 structurally (x = eta = ceta * rho):
+// P, P', P'' by the three-term recurrence (3 FMA per coefficient instead of a full D2 product).
+template <int N>
+PCS_DEV D2<double> horner_lin(const double* coef, const D2<double>& x) {
+    double p = coef[N - 1], d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int i = N - 2; i >= 0; i--) {
+        d2 = __builtin_fma(d2, x.v, d1);
+        d1 = __builtin_fma(d1, x.v, p);
+        p = __builtin_fma(p, x.v, coef[i]);
+    }
+    return D2<double>(p, d1 * x.d1, 2.0 * d2 * (x.d1 * x.d1));
+}
+// generic fall-back (gradient kernels): plain Horner in R arithmetic
+template <int N, class P, class R>
+PCS_DEV R horner_eta(const P* coef, const R& x) { return horner<N>(coef, x); }
+template <int N>
+PCS_DEV D2<double> horner_eta(const double* coef, const D2<double>& x) { return horner_lin<N>(coef, x); }
+
 template <class R>
 PCS_DEV R site_term(const R& x) {  // ln x - x/2 + 1/2   (:176)
     return d_log(x) - 0.5 * x + 0.5;
@@ -118,8 +137,8 @@ PCS_DEV R pure_a(const PureCoef<P>& c, const R& rho) {
     R hc = (rho * c.mm1) * d_log(g);
 
     // dispersion (:125-142)
-    R I1 = horner<7>(c.ai, eta);
-    R I2 = horner<7>(c.bi, eta);
+    R I1 = horner_eta<7>(c.ai, eta);
+    R I2 = horner_eta<7>(c.bi, eta);
     R eta_m4 = eta_m2 * eta_m2;
     R t2 = eta_m1 * d_recip(2.0 - eta);
     R poly = eta * (20.0 + eta * (-27.0 + eta * (12.0 - 2.0 * eta)));
@@ -129,8 +148,8 @@ PCS_DEV R pure_a(const PureCoef<P>& c, const R& rho) {
 
     // dipoles (:145-160)
     if (c.polar) {
-        R J1 = horner<5>(c.j1, eta);
-        R J2 = horner<4>(c.j2, eta);
+        R J1 = horner_eta<5>(c.j1, eta);
+        R J2 = horner_eta<4>(c.j2, eta);
         a = a + (rho2 * c.qm) * ((J1 * J1) * d_recip(J1 - rho * J2));
     }
 

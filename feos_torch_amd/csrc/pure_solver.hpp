@@ -17,6 +17,12 @@
 #pragma once
 #include "pure_model.hpp"
 
+#ifdef PCS_NO_NANPROOF
+#define PCS_NP(...)
+#else
+#define PCS_NP(...) __VA_ARGS__
+#endif
+
 namespace pcs {
 
 enum : int { ST_OK = 0, ST_FAILED = 1, ST_RETRY = 2 };
@@ -66,13 +72,13 @@ PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, 
                 rho = 0.62 / c.ceta;
                 e = pure_eval(c, rho);
             }
-            if (!(e.dp > 0.0) || !(e.p == e.p)) {
+            if (PCS_NP(!is_finite_bits(e.dp) ||) !(e.dp > 0.0) || !is_finite_bits(e.p)) {
                 fail = true;
             } else {
                 double step = (e.p - p_spec) / e.dp;
                 last = e;
                 double rho_new = rho - step;
-                if (!(rho_new > 0.0)) {
+                if (PCS_NP(!is_finite_bits(rho_new) ||) !(rho_new > 0.0)) {
                     fail = true;
                 } else {
                     done = fabs(step) <= tol * rho;
@@ -126,10 +132,10 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
     {
         double mu;
         l = pure_eval_mu(c, rl, mu);  // all lanes (wave-uniform call); also the first liquid evaluation
-        if (!(l.dp > 0.0)) active = false;
+        if (PCS_NP(!is_finite_bits(l.dp) ||) !(l.dp > 0.0) PCS_NP(|| !is_finite_bits(mu))) active = false;
         rv = rl * exp(mu);  // ln rho_V = ln rho_L + a'(rho_L): ideal vapour at the liquid's fugacity
         // strongly non-ideal vapour estimates are left to the robust path
-        if (!(rv < 0.05 * rl)) active = false;
+        if (PCS_NP(!is_finite_bits(rv) ||) !(rv < 0.05 * rl)) active = false;
     }
     bool done = false;
     out.iters = 0;
@@ -137,7 +143,7 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
         if (active && !done) {
             Eval v = pure_eval(c, rv);
             VleStep s = vle_step(l, v, rl, rv);
-            bool ok = (l.dp > 0.0) && (v.dp > 0.0) && (s.p_star == s.p_star);
+            bool ok = PCS_NP(is_finite_bits(l.dp) && is_finite_bits(v.dp) &&) (l.dp > 0.0) && (v.dp > 0.0) && is_finite_bits(s.p_star) && is_finite_bits(s.dl) && is_finite_bits(s.dv);
             double rl_new = rl + s.dl, rv_new = rv + s.dv;
             ok = ok && (rl_new > 0.0) && (rv_new > 0.0) && (rv_new < rl_new);
             if (!ok) {
@@ -163,11 +169,14 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
 // Robust path (rare rows: near-critical temperatures, strongly non-ideal vapour).  Lane-serial
 // bisections; no wave-uniform tricks needed because it runs on a compacted list of few rows.
 // ---------------------------------------------------------------------------------------------
+// x > 0 that is false for NaN even when the compiler may assume there are no NaNs
+PCS_DEV bool gt0(double x) { return is_finite_bits(x) && x > 0.0; }
+
 PCS_DEV double branch_solve(const PureCoef<double>& c, double p_spec, double lo, double hi, double rho) {
     for (int it = 0; it < 100; it++) {
         Eval e = pure_eval(c, rho);
         if (e.p > p_spec) hi = rho; else lo = rho;
-        double rho_new = (e.dp > 0.0) ? rho - (e.p - p_spec) / e.dp : -1.0;
+        double rho_new = gt0(e.dp) ? rho - (e.p - p_spec) / e.dp : -1.0;
         if (!(rho_new > lo && rho_new < hi)) rho_new = 0.5 * (lo + hi);
         double diff = fabs(rho_new - rho);
         rho = rho_new;
@@ -180,7 +189,7 @@ PCS_DEV double spinodal_bisect(const PureCoef<double>& c, double lo, double hi, 
     for (int it = 0; it < 50; it++) {
         double mid = 0.5 * (lo + hi);
         Eval e = pure_eval(c, mid);
-        if ((e.dp > 0.0) == dp_positive_at_lo) lo = mid; else hi = mid;
+        if (gt0(e.dp) == dp_positive_at_lo) lo = mid; else hi = mid;
     }
     return 0.5 * (lo + hi);
 }
@@ -196,10 +205,10 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
         bool ok = true;
         for (int it = 0; it < 100; it++) {
             Eval e = pure_eval(c, rho);
-            if (!(e.dp > 0.0) || !(e.p == e.p)) { ok = false; break; }
+            if (!gt0(e.dp) || !is_finite_bits(e.p)) { ok = false; break; }
             double step = e.p / e.dp;
             double rho_new = rho - step;
-            if (!(rho_new > 0.0)) { ok = false; break; }
+            if (!gt0(rho_new)) { ok = false; break; }
             bool conv = fabs(step) <= 1e-8 * rho;
             rho = rho_new;
             if (conv) break;
@@ -207,12 +216,12 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
         if (ok) {
             double mu;
             Eval e = pure_eval_mu(c, rho, mu);
-            if (e.dp > 0.0) {
+            if (gt0(e.dp)) {
                 rl = rho;
                 rv = rl * exp(mu);
                 for (int k = 0; k < 60; k++) {
                     Eval v = pure_eval(c, rv);
-                    if (v.dp > 0.0 && v.p > 0.0 && rv < 0.5 * rl) { have_init = true; break; }
+                    if (gt0(v.dp) && gt0(v.p) && rv < 0.5 * rl) { have_init = true; break; }
                     rv *= 0.5;
                 }
             }
@@ -224,7 +233,7 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
         bool found = false;
         for (int k = 0; k < 400; k++) {
             Eval e = pure_eval(c, rho);
-            if (!(e.dp > 0.0)) { found = true; break; }
+            if (!gt0(e.dp)) { found = true; break; }
             rho_stable = rho;
             rho *= 0.97;
         }
@@ -235,13 +244,13 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
         for (int k = 0; k < 2000; k++) {
             rho *= 0.97;
             Eval e = pure_eval(c, rho);
-            if (e.dp > 0.0) { found = true; break; }
+            if (gt0(e.dp)) { found = true; break; }
             rho_unstable = rho;
         }
         if (!found) return ST_FAILED;
         double rho_sv = spinodal_bisect(c, rho, rho_unstable, true);
         double p_sl = pure_eval(c, rho_sl).p, p_sv = pure_eval(c, rho_sv).p;
-        if (!(p_sv > 0.0)) return ST_FAILED;
+        if (!gt0(p_sv)) return ST_FAILED;
         double p0 = 0.5 * ((p_sl > 0.0 ? p_sl : 0.0) + p_sv);
         double hi = 0.6 / c.ceta;
         rl = branch_solve(c, p0, rho_sl, hi, 0.5 * (rho_sl + hi));
@@ -257,13 +266,13 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
         double rl_new = rl + dl, rv_new = rv + dv;
         bool damped = false;
         for (int k = 0; k < 40; k++) {
-            if (rl_new > 0.0 && pure_eval(c, rl_new).dp > 0.0) break;
+            if (gt0(rl_new) && gt0(pure_eval(c, rl_new).dp)) break;
             dl *= 0.5;
             rl_new = rl + dl;
             damped = true;
         }
         for (int k = 0; k < 40; k++) {
-            if (rv_new > 0.0 && pure_eval(c, rv_new).dp > 0.0) break;
+            if (gt0(rv_new) && gt0(pure_eval(c, rv_new).dp)) break;
             dv *= 0.5;
             rv_new = rv + dv;
             damped = true;
@@ -275,7 +284,7 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
         out.rho_l = rl;
         out.p_star = s.p_corr;
         out.iters = it + 1;
-        if (!(rl == rl) || !(rv == rv)) return ST_FAILED;
+        if (!is_finite_bits(rl) || !is_finite_bits(rv)) return ST_FAILED;
         bool stagnated = it >= 3 && err < 1e-7 && err >= 0.25 * err_prev;
         err_prev = err;
         if (!damped && (err <= TOL_STEP || stagnated)) {
