@@ -10,10 +10,12 @@ SOURCES = ["pure_kernels.hip", "pure_robust.hip", "mix_kernels.hip", "gc_kernels
 # numbers (0 * x, x + 0); every NaN/inf test in the kernels is a bit test (is_finite_bits), so the
 # failure detection does not depend on IEEE comparison semantics.  Measured on k_pure_vle: x1.065,
 # x1.158 together with the v_rcp_f64 + Newton reciprocal (scratch A/B, 1e7 rows, MI355X).
+# -DPCS_F32_PRESOLVE: fp32 initialiser + first Newton iterations of the VLE (csrc/pure_f32.hpp): x1.16
+# on k_pure_vle and the robust-pass list shrinks 82,010 -> 184 rows per 1e7.
 # They are applied to the pure-component translation unit only (the headline kernel); the
 # mixture / gc solvers keep strict IEEE comparisons.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
-RELAXED = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros", "-DPCS_FAST_RCP"]
+RELAXED = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros", "-DPCS_FAST_RCP", "-DPCS_F32_PRESOLVE"]
 RELAXED_SOURCES = {"pure_kernels.hip"}
 
 

@@ -1,0 +1,186 @@
+// fp32 pre-solve of the pure-component VLE (device only).
+//
+// On gfx950 an fp32 VALU op issues in half the cycles of an fp64 one and 1/x, log, sqrt are single
+// (quarter-rate) instructions instead of ~5 / ~45 / ~20-instruction fp64 sequences, so one fp32
+// evaluation of a(rho), a', a'' costs ~0.35 of the fp64 one.  Newton's method is self-correcting:
+// the zero-pressure liquid root, the ideal-gas vapour estimate and the first coupled iterations
+// are therefore run in fp32 down to its noise floor (~1e-6 relative), and the fp64 iteration of
+// pure_solver.hpp starts from that point and needs 1-2 iterations instead of 4-5 + initialiser.
+// The result is defined by the fp64 iterations alone; a lane whose fp32 pass leaves the
+// representable range or misbehaves simply takes the all-fp64 path.
+#pragma once
+#include "pure_model.hpp"
+
+namespace pcs {
+
+struct F2 {  // value, d/drho, d2/drho2 in fp32
+    float v, d1, d2;
+};
+PCS_DEV F2 f2(float v, float d1, float d2) { F2 r; r.v = v; r.d1 = d1; r.d2 = d2; return r; }
+PCS_DEV F2 operator+(F2 a, F2 b) { return f2(a.v + b.v, a.d1 + b.d1, a.d2 + b.d2); }
+PCS_DEV F2 operator-(F2 a, F2 b) { return f2(a.v - b.v, a.d1 - b.d1, a.d2 - b.d2); }
+PCS_DEV F2 operator+(F2 a, float b) { return f2(a.v + b, a.d1, a.d2); }
+PCS_DEV F2 operator-(float b, F2 a) { return f2(b - a.v, -a.d1, -a.d2); }
+PCS_DEV F2 operator*(F2 a, float b) { return f2(a.v * b, a.d1 * b, a.d2 * b); }
+PCS_DEV F2 operator*(F2 a, F2 b) {
+    return f2(a.v * b.v, fmaf(a.d1, b.v, a.v * b.d1), fmaf(a.d2, b.v, fmaf(2.0f * a.d1, b.d1, a.v * b.d2)));
+}
+PCS_DEV F2 chainf(F2 a, float f0, float f1, float f2_) { return f2(f0, f1 * a.d1, fmaf(f2_, a.d1 * a.d1, f1 * a.d2)); }
+PCS_DEV F2 recipf(F2 a) {
+    float r = __builtin_amdgcn_rcpf(a.v);
+    float r2 = r * r;
+    return chainf(a, r, -r2, 2.0f * r2 * r);
+}
+PCS_DEV F2 logf2(F2 a) {
+    float r = __builtin_amdgcn_rcpf(a.v);
+    return chainf(a, __logf(a.v), r, -r * r);
+}
+PCS_DEV F2 sqrtf2(F2 a) {
+    float s = __builtin_amdgcn_sqrtf(a.v);
+    float h = 0.5f * __builtin_amdgcn_rcpf(s);
+    return chainf(a, s, h, -0.5f * h * __builtin_amdgcn_rcpf(a.v));
+}
+template <int N>
+PCS_DEV F2 hornerf(const float* coef, F2 x) {  // x.d2 == 0 (x = eta = ceta * rho)
+    float p = coef[N - 1], d1 = 0.0f, d2 = 0.0f;
+#pragma unroll
+    for (int i = N - 2; i >= 0; i--) {
+        d2 = fmaf(d2, x.v, d1);
+        d1 = fmaf(d1, x.v, p);
+        p = fmaf(p, x.v, coef[i]);
+    }
+    return f2(p, d1 * x.d1, 2.0f * d2 * (x.d1 * x.d1));
+}
+
+struct PureCoefF {
+    float m, mm1, ceta, ai[7], bi[7], kd1, kd2, j1[5], j2[4], qm, da, na, nb;
+    bool polar, assoc;
+};
+
+PCS_DEV void to_f32(const PureCoef<double>& c, PureCoefF& f) {
+    f.m = (float)c.m; f.mm1 = (float)c.mm1; f.ceta = (float)c.ceta;
+#pragma unroll
+    for (int i = 0; i < 7; i++) { f.ai[i] = (float)c.ai[i]; f.bi[i] = (float)c.bi[i]; }
+    f.kd1 = (float)c.kd1; f.kd2 = (float)c.kd2;
+    f.polar = c.polar; f.assoc = c.assoc;
+    if (c.polar) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) f.j1[i] = (float)c.j1[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) f.j2[i] = (float)c.j2[i];
+        f.qm = (float)c.qm;
+    }
+    f.da = (float)c.da; f.na = (float)c.na; f.nb = (float)c.nb;
+}
+
+struct EvalF { float a, p, dp, mu; };
+
+// same model as pure_a() (pure_model.hpp), fp32
+PCS_DEV EvalF pure_eval_f32(const PureCoefF& c, float rho) {
+    F2 r = f2(rho, 1.0f, 0.0f);
+    F2 eta = r * c.ceta;
+    F2 eta2 = eta * eta;
+    F2 om = 1.0f - eta;
+    F2 eta_m1 = recipf(om);
+    F2 eta_m2 = eta_m1 * eta_m1;
+    F2 hs = (r * c.m) * (((eta * 4.0f) - (eta2 * 3.0f)) * eta_m2);
+    F2 g = (1.0f - (eta * 0.5f)) * (eta_m1 * eta_m2);
+    F2 hc = (r * c.mm1) * logf2(g);
+    F2 I1 = hornerf<7>(c.ai, eta);
+    F2 I2 = hornerf<7>(c.bi, eta);
+    F2 eta_m4 = eta_m2 * eta_m2;
+    F2 t2 = eta_m1 * recipf(2.0f - eta);
+    F2 poly = eta * ((eta * ((eta * ((eta * -2.0f) + 12.0f)) + -27.0f)) + 20.0f);
+    F2 C1 = recipf((((eta * ((eta * -2.0f) + 8.0f)) * eta_m4) * c.m) - ((poly * (t2 * t2)) * c.mm1) + 1.0f);
+    F2 rho2 = r * r;
+    F2 a = hs - hc + rho2 * ((I1 * c.kd1) + ((C1 * I2) * c.kd2));
+    if (c.polar) {
+        F2 J1 = hornerf<5>(c.j1, eta);
+        F2 J2 = hornerf<4>(c.j2, eta);
+        a = a + (rho2 * c.qm) * ((J1 * J1) * recipf(J1 - r * J2));
+    }
+    if (c.assoc) {
+        F2 k = eta * eta_m1;
+        F2 delta = (((k * ((k * 0.5f) + 1.5f)) + 1.0f) * eta_m1) * c.da;
+        F2 rhoa = r * c.na, rhob = r * c.nb;
+        F2 t = (rhob - rhoa) * delta;
+        F2 aux = 1.0f - t;
+        F2 sq = sqrtf2(aux * aux + (rhob * delta) * 4.0f);
+        F2 xa, xb;
+        if (t.v > 0.5f) {
+            xa = recipf(sq + t + 1.0f) * 2.0f;
+            xb = (sq + t + -1.0f) * recipf((rhob * delta) * 2.0f);
+        } else if (t.v < -0.5f) {
+            xa = (sq - t + -1.0f) * recipf((rhoa * delta) * 2.0f);
+            xb = recipf(sq - t + 1.0f) * 2.0f;
+        } else {
+            xa = recipf(sq + t + 1.0f) * 2.0f;
+            xb = recipf(sq - t + 1.0f) * 2.0f;
+        }
+        a = a + rhoa * (logf2(xa) - (xa * 0.5f) + 0.5f) + rhob * (logf2(xb) - (xb * 0.5f) + 0.5f);
+    }
+    EvalF e;
+    e.a = a.v;
+    e.p = rho - a.v + rho * a.d1;
+    e.dp = 1.0f + rho * a.d2;
+    e.mu = a.d1;
+    return e;
+}
+
+PCS_DEV bool finitef(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
+
+// fp32 pass.  Returns true with (rl, rv) close to the solution (typically 1e-6 relative) when
+// every step of the pass behaved; false = this lane must use the fp64 initialiser.
+PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double& rv_out) {
+    PureCoefF f;
+    to_f32(c, f);
+    bool ok = finitef(f.da) && finitef(f.kd2) && finitef(f.ceta) && f.ceta > 0.0f;
+    // zero-pressure liquid, Newton from eta = 0.5 (monotone from the dense side)
+    float rl = 0.5f / f.ceta;
+    bool done = !ok;
+    for (int it = 0; it < 12; it++) {
+        if (!done) {
+            EvalF e = pure_eval_f32(f, rl);
+            if (!finitef(e.p) || !(e.dp > 0.0f) || (it == 0 && !(e.p > 0.0f))) {
+                ok = false;
+                done = true;
+            } else {
+                float step = e.p / e.dp;
+                float rn = rl - step;
+                if (!(rn > 0.0f)) { ok = false; done = true; }
+                else { done = fabsf(step) <= 2e-4f * rl; rl = rn; }
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+    }
+    EvalF l = pure_eval_f32(f, rl);
+    float rv = rl * __expf(l.mu);
+    ok = ok && done && finitef(rv) && (l.dp > 0.0f) && (rv < 0.5f * rl) && (rv > 1e-30f);
+    // coupled Newton towards the equal-area pressure, to the fp32 noise floor
+    done = !ok;
+    for (int it = 0; it < 8; it++) {
+        if (!done) {
+            EvalF v = pure_eval_f32(f, rv);
+            float iv = __builtin_amdgcn_rcpf(rv), il = __builtin_amdgcn_rcpf(rl);
+            float ps = -(v.a * iv - l.a * il + __logf(rv * il)) * __builtin_amdgcn_rcpf(iv - il);
+            float dl = -(l.p - ps) * __builtin_amdgcn_rcpf(l.dp);
+            float dv = -(v.p - ps) * __builtin_amdgcn_rcpf(v.dp);
+            float rln = rl + dl, rvn = rv + dv;
+            if (!finitef(rln) || !finitef(rvn) || !(v.dp > 0.0f) || !(l.dp > 0.0f) || !(rvn > 1e-30f) || !(rvn < 0.6f * rln)) {
+                ok = false;
+                done = true;
+            } else {
+                done = (fabsf(dl) <= 2e-6f * rl) && (fabsf(dv) <= 3e-5f * rv);
+                rl = rln;
+                rv = rvn;
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+        if (!done) l = pure_eval_f32(f, rl);
+    }
+    rl_out = (double)rl;
+    rv_out = (double)rv;
+    return ok;  // not converged within the caps is fine: the fp64 iteration continues from here
+}
+
+}  // namespace pcs

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void k_pure_vle_robust(const double* __restrict
         PureCoef<double> c;
         pure_coef<double>(c, par, T, false);
         VleResult r;
-        int st = vle_robust(c, r);
+        int st = vle_robust(c, r, rho_eq ? 1e-8 : TOL_STEP);
         if (st == ST_OK) {
             if (p_sat) p_sat[i] = r.p_star * T * P_UNIT;
             if (rho_eq) rho_eq[i] = r.rho_l * (1.0 / RHO_UNIT);

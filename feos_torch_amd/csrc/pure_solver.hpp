@@ -16,6 +16,7 @@
 // __ballot(!done) == 0 (or the iteration cap).
 #pragma once
 #include "pure_model.hpp"
+#include "pure_f32.hpp"
 
 #ifdef PCS_NO_NANPROOF
 #define PCS_NP(...)
@@ -61,9 +62,10 @@ constexpr double TOL_STEP = 1e-6;  // relative Newton step at which a lane is co
 // formula rho - (p - p_spec)/dp of pcsaft_pure.py:198), ST_FAILED when the liquid branch has
 // no root at this pressure (iterate crossed the spinodal), or when the cap is hit.
 // `tol` is loose (1e-6) when used as an initialiser.
-PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, double& rho, Eval& last) {
+// `skip` lanes idle through the (wave-uniform) loop and return ST_OK untouched.
+PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, double& rho, Eval& last, bool skip = false) {
     rho = ETA_START / c.ceta;
-    bool done = false, fail = false;
+    bool done = skip, fail = false;
     for (int it = 0; it < LIQ_MAX_IT; it++) {
         if (!done && !fail) {
             Eval e = pure_eval(c, rho);
@@ -123,22 +125,40 @@ PCS_DEV VleStep vle_step(const Eval& l, const Eval& v, double rl, double rv) {
 // Fast path of the pure VLE: zero-pressure liquid + ideal-gas vapour initialisation, then the
 // coupled Newton.  ST_RETRY = this initialisation does not apply (near-critical temperature);
 // the robust kernel takes those rows.
-PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
-    double rl;
+// tol_l: relative liquid step at which a lane stops.  TOL_STEP suffices for the pressure (second-order
+// corrected); the saturated liquid density itself is only as good as the last step squared, so the
+// caller passes a tighter value when that output is requested.
+PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = TOL_STEP) {
+    double rl = 0.0, rv = 0.0;
     Eval l;
-    int st = liquid_newton(c, 0.0, 1e-3, rl, l);
-    bool active = (st == ST_OK);
-    double rv = 0.0;
+    bool warm = false;
+#ifdef PCS_F32_PRESOLVE
+    warm = vle_presolve_f32(c, rl, rv);  // fp32 initialiser + first iterations (pure_f32.hpp)
+#endif
+    bool active = warm;
+    if (__ballot(!warm) != 0ull) {
+        // lanes without a usable fp32 result: fp64 zero-pressure liquid (the others idle through it)
+        double rl0;
+        int st = liquid_newton(c, 0.0, 1e-3, rl0, l, warm);
+        if (!warm) {
+            rl = rl0;
+            active = (st == ST_OK);
+        }
+    }
     {
         double mu;
         l = pure_eval_mu(c, rl, mu);  // all lanes (wave-uniform call); also the first liquid evaluation
-        if (PCS_NP(!is_finite_bits(l.dp) ||) !(l.dp > 0.0) PCS_NP(|| !is_finite_bits(mu))) active = false;
-        rv = rl * exp(mu);  // ln rho_V = ln rho_L + a'(rho_L): ideal vapour at the liquid's fugacity
+        if (!is_finite_bits(l.dp) || !(l.dp > 0.0) || !is_finite_bits(mu)) active = false;
+        if (!warm) rv = rl * exp(mu);  // ln rho_V = ln rho_L + a'(rho_L): ideal vapour at the liquid's fugacity
         // strongly non-ideal vapour estimates are left to the robust path
-        if (PCS_NP(!is_finite_bits(rv) ||) !(rv < 0.05 * rl)) active = false;
+        // (a warm lane carries a converged fp32 vapour density instead: only sanity-checked)
+        if (!is_finite_bits(rv) || !(rv < (warm ? 0.7 : 0.05) * rl)) active = false;
     }
     bool done = false;
     out.iters = 0;
+#ifdef PCS_DEBUG_CODES
+    if (!active) { out.iters = warm ? 20 : 10; out.rho_v = rv; out.rho_l = rl; }
+#endif
     for (int it = 0; it < VLE_MAX_IT; it++) {
         if (active && !done) {
             Eval v = pure_eval(c, rv);
@@ -148,8 +168,11 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
             ok = ok && (rl_new > 0.0) && (rv_new > 0.0) && (rv_new < rl_new);
             if (!ok) {
                 active = false;
+#ifdef PCS_DEBUG_CODES
+                out.iters = 100 + it + (warm ? 50 : 0); out.rho_v = rv; out.rho_l = rl;
+#endif
             } else {
-                done = (fabs(s.dl) <= TOL_STEP * rl) && (fabs(s.dv) <= TOL_STEP * rv);
+                done = (fabs(s.dl) <= tol_l * rl) && (fabs(s.dv) <= TOL_STEP * rv);
                 rl = rl_new;
                 rv = rv_new;
                 out.rho_v = rv;
@@ -161,8 +184,8 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
         if (__ballot(active && !done) == 0ull) break;
         if (active && !done) l = pure_eval(c, rl);
     }
-    if (done) return ST_OK;
-    return ST_RETRY;  // includes cap hit: let the robust path decide
+    if (done && out.rho_v < 0.7 * out.rho_l) return ST_OK;
+    return ST_RETRY;  // includes cap hit and near-critical states: let the robust path decide
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -173,7 +196,7 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out) {
 PCS_DEV bool gt0(double x) { return is_finite_bits(x) && x > 0.0; }
 
 PCS_DEV double branch_solve(const PureCoef<double>& c, double p_spec, double lo, double hi, double rho) {
-    for (int it = 0; it < 100; it++) {
+    for (int it = 0; it < 60; it++) {
         Eval e = pure_eval(c, rho);
         if (e.p > p_spec) hi = rho; else lo = rho;
         double rho_new = gt0(e.dp) ? rho - (e.p - p_spec) / e.dp : -1.0;
@@ -186,7 +209,7 @@ PCS_DEV double branch_solve(const PureCoef<double>& c, double p_spec, double lo,
 }
 
 PCS_DEV double spinodal_bisect(const PureCoef<double>& c, double lo, double hi, bool dp_positive_at_lo) {
-    for (int it = 0; it < 50; it++) {
+    for (int it = 0; it < 26; it++) {  // 2^-26 of the bracket: the spinodals only seed the branch solves
         double mid = 0.5 * (lo + hi);
         Eval e = pure_eval(c, mid);
         if (gt0(e.dp) == dp_positive_at_lo) lo = mid; else hi = mid;
@@ -194,7 +217,7 @@ PCS_DEV double spinodal_bisect(const PureCoef<double>& c, double lo, double hi, 
     return 0.5 * (lo + hi);
 }
 
-PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
+PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out, double tol_l = TOL_STEP) {
     double rl, rv;
     Eval el;
     // 1. try the zero-pressure liquid with a tight tolerance and pull the vapour guess back
@@ -203,7 +226,7 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
     {
         double rho = ETA_START / c.ceta;
         bool ok = true;
-        for (int it = 0; it < 100; it++) {
+        for (int it = 0; it < 40; it++) {
             Eval e = pure_eval(c, rho);
             if (!gt0(e.dp) || !is_finite_bits(e.p)) { ok = false; break; }
             double step = e.p / e.dp;
@@ -231,18 +254,19 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
     if (!have_init) {
         double rho = ETA_START / c.ceta, rho_stable = rho;
         bool found = false;
-        for (int k = 0; k < 400; k++) {
+        // geometric scans (this pass is latency-bound by its slowest row: keep the evaluation count low)
+        for (int k = 0; k < 60; k++) {
             Eval e = pure_eval(c, rho);
             if (!gt0(e.dp)) { found = true; break; }
             rho_stable = rho;
-            rho *= 0.97;
+            rho *= 0.9;
         }
         if (!found) return ST_FAILED;  // super-critical
         double rho_sl = spinodal_bisect(c, rho, rho_stable, false);
         double rho_unstable = rho;
         found = false;
-        for (int k = 0; k < 2000; k++) {
-            rho *= 0.97;
+        for (int k = 0; k < 120; k++) {
+            rho *= 0.8;
             Eval e = pure_eval(c, rho);
             if (gt0(e.dp)) { found = true; break; }
             rho_unstable = rho;
@@ -258,26 +282,26 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out) {
     }
     // 3. coupled Newton with backtracking onto the stable branches
     double err_prev = 1.0;
-    for (int it = 0; it < 100; it++) {
+    for (int it = 0; it < 60; it++) {
         Eval l = pure_eval(c, rl);
         Eval v = pure_eval(c, rv);
         VleStep s = vle_step(l, v, rl, rv);
         double dl = s.dl, dv = s.dv;
         double rl_new = rl + dl, rv_new = rv + dv;
         bool damped = false;
-        for (int k = 0; k < 40; k++) {
+        for (int k = 0; k < 12; k++) {
             if (gt0(rl_new) && gt0(pure_eval(c, rl_new).dp)) break;
             dl *= 0.5;
             rl_new = rl + dl;
             damped = true;
         }
-        for (int k = 0; k < 40; k++) {
+        for (int k = 0; k < 12; k++) {
             if (gt0(rv_new) && gt0(pure_eval(c, rv_new).dp)) break;
             dv *= 0.5;
             rv_new = rv + dv;
             damped = true;
         }
-        double err = fmax(fabs(dl) / rl, fabs(dv) / rv);
+        double err = fmax(fabs(dl) / rl * (TOL_STEP / tol_l), fabs(dv) / rv);
         rl = rl_new;
         rv = rv_new;
         out.rho_v = rv;
