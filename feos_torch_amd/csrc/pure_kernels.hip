@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) void k_pure_vle(const double* __restrict__ p
     PureCoef<double> c;
     pure_coef<double>(c, par, T, false);
     VleResult r;
-    int st = vle_fast(c, r, rho_eq ? 1e-8 : TOL_STEP);  // wave-uniform
+    int st = rho_eq ? vle_fast(c, r, 1e-8, TOL_STEP) : vle_fast(c, r);  // wave-uniform
 
     if (!live) return;
     if (st == ST_OK) {
