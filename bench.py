@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 
 BYTES_PER_SOLVE = 81  # 64 B parameters + 8 B T read, 8 B p_sat + 1 B status written
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (FMA = 2 flop)
+FP64_FMA_PEAK_GWAVEINSTR = 457.0  # measured on MI355X: independent v_fma_f64 chains, G wave-instructions/s (scratch/valu_peak.hip)
 
 
 def parse():
@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--chunks", type=int, default=4, help="sub-batches per step (gather/solve overlap, N>1)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="rows of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=40_000_000, help="upper bound on the rows of the CPU baseline sample")
     return ap.parse_args()
 
 
@@ -56,17 +56,18 @@ def relaunch_under_torchrun(args):
     sys.exit(subprocess.call(cmd))
 
 
-def load_pmc_traffic(rows):
-    """HBM bytes per k_pure_vle launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+def load_pmc(rows):
+    """Counter-derived figures of k_pure_vle from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json):
+    HBM bytes per launch and VALU wave-instructions per launch.  {} if absent or for another launch size."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
         if int(d.get("rows", -1)) == int(rows):
-            return d.get("hbm_bytes_per_launch")
+            return d
     except Exception:
         pass
-    return None
+    return {}
 
 
 def main():
@@ -115,8 +116,8 @@ def main():
                 ev1[i * nchunk + k].record()
             plans[k].run_retry(Pc[k], Tc[k])
             if gather:  # NCCL stream waits for the kernels above, the next chunk's solve overlaps it
-                works.append(dist.all_gather_into_tensor(g_p[k], plans[k].p_sat, async_op=True))
-                works.append(dist.all_gather_into_tensor(g_s[k], plans[k].status, async_op=True))
+                works.append(pdist.all_gather_flat(g_p[k], plans[k].p_sat, async_op=True))
+                works.append(pdist.all_gather_flat(g_s[k], plans[k].status, async_op=True))
         for w in works:
             w.wait()
 
@@ -147,7 +148,9 @@ def main():
         total = world * rows * args.steps
         value = total / dt
         achieved = BYTES_PER_SOLVE * crow / (kern_ms * 1e-3) / 1e9
-        traffic = load_pmc_traffic(crow)
+        pmc = load_pmc(crow)
+        traffic = pmc.get("hbm_bytes_per_launch")
+        valu = pmc.get("valu_wave_instr_per_launch")
         line = {
             "metric": "pc_saft_pure_vapor_pressure_solves_per_sec",
             "value": value,
@@ -181,14 +184,31 @@ def main():
                 "bytes_per_solve": BYTES_PER_SOLVE,
                 "rows_per_launch": crow,
                 "kernel_ms": kern_ms,
-                "note": "path is fp64-VALU bound (arithmetic intensity >> machine balance); see DESIGN.md",
+                "note": "path is VALU-issue bound (arithmetic intensity >> machine balance); see DESIGN.md",
+                # the roofline that actually bounds the kernel: VALU issue.  Counted wave-instructions (PMC
+                # SQ_INSTS_VALU, profiles/) / measured kernel time vs the measured v_fma_f64 issue peak
+                # (the kernel mixes fp32 and fp64 VALU, so the fraction can exceed what fp64 alone allows)
+                "valu": None if not valu else {
+                    "wave_instr_per_launch": valu,
+                    "instr_per_solve": valu * 64.0 / crow,
+                    "achieved_gwaveinstr_s": valu / (kern_ms * 1e-3) / 1e9,
+                    "fp64_fma_peak_gwaveinstr_s": FP64_FMA_PEAK_GWAVEINSTR,
+                    "valu_busy_pmc": pmc.get("valu_busy"),
+                },
             },
         }
         if not args.no_cpu_baseline and world == 1:
+            # OpenMP threads = CPUs this process may use (affinity mask capped by the cgroup quota)
+            from oracle import pyoracle as _o
+            os.environ.setdefault("OMP_NUM_THREADS", str(_o.usable_cpus()))
             from oracle import pyoracle as orc
 
-            ns = min(args.cpu_sample, rows)
             orc.pure_vapor_pressure(P[:1000], T[:1000], prec=0)  # load + warm
+            # size the sample for ~10 s of wall time on this host (bounded by --cpu-sample and the batch)
+            t1 = time.perf_counter()
+            orc.pure_vapor_pressure(P[:200_000], T[:200_000], prec=0)
+            probe_rate = 200_000 / (time.perf_counter() - t1)
+            ns = int(min(rows, args.cpu_sample, max(200_000, probe_rate * 10.0)))
             t1 = time.perf_counter()
             orc.pure_vapor_pressure(P[:ns], T[:ns], prec=0)
             ct = time.perf_counter() - t1

@@ -23,6 +23,10 @@ def init_from_env():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    # rehearsal on a 1-GPU box: PCS_SINGLE_DEVICE=1 maps every rank to cuda:0 (use with PCS_DIST_BACKEND=gloo,
+    # RCCL refuses two ranks on one device)
+    if os.environ.get("PCS_SINGLE_DEVICE") == "1":
+        local = 0
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
@@ -30,10 +34,11 @@ def init_from_env():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if use_cuda:
+        backend = os.environ.get("PCS_DIST_BACKEND", "nccl" if use_cuda else "gloo")
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
@@ -42,6 +47,15 @@ def shard_bounds(n, rank, world):
     lo = (n * rank) // world
     hi = (n * (rank + 1)) // world
     return lo, hi
+
+
+def all_gather_flat(recv, send, group=None, async_op=False):
+    """all_gather of equal-size 1-D shards into a flat [world * len] tensor.  RCCL: one
+    ncclAllGather (all_gather_into_tensor); gloo: list form on views of `recv`."""
+    if dist.get_backend(group) == "nccl":
+        return dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+    world = dist.get_world_size(group)
+    return dist.all_gather(list(recv.view(world, -1).unbind(0)), send, group=group, async_op=async_op)
 
 
 def gather_rows(local, n_total, group=None):

@@ -78,6 +78,19 @@ def num_threads():
     return lib().orc_num_threads()
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def _c(x, shape=None):
     x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
     if shape is not None:

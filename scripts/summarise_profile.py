@@ -61,6 +61,8 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         allc.setdefault(k, {})[c] = sum(v) / len(v)
     meta.update(m)
 traffic = None
+valu_instr = None
+valu_busy = None
 for k, c in allc.items():
     if "k_pure" not in k and "k_mix" not in k and "k_gc" not in k:
         continue
@@ -74,13 +76,18 @@ for k, c in allc.items():
             traffic = hbm
     if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
         lines.append(f"| VALU instructions per wave (= per state point) | {c['SQ_INSTS_VALU']/c['SQ_WAVES']:.1f} |")
+        if "k_pure_vle(" in k:
+            valu_instr = c["SQ_INSTS_VALU"]
     if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         # SQ_ACTIVE_INST_* count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over 8 XCDs
         simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
         lines.append(f"| VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE/8) | {c['SQ_ACTIVE_INST_VALU']*4/simd_cycles:.3f} |")
+        if "k_pure_vle(" in k:
+            valu_busy = c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 if traffic is not None:
     json.dump({"tag": tag, "kernel": "k_pure_vle", "rows": 10_000_000, "hbm_bytes_per_launch": traffic,
+               "valu_wave_instr_per_launch": valu_instr, "valu_busy": valu_busy,
                "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH correction"},
               open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
