@@ -39,27 +39,14 @@ __device__ __forceinline__ GcTable stage_table(const double* __restrict__ table,
     return tb;
 }
 
+constexpr int GC_FAST_SS = 12, GC_FAST_NEWTON = 10;  // fast-pass caps (mix_solver.hpp)
+constexpr int GC_RETRY_BLOCKS = 1024;
+
 template <bool DEW>
-__global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restrict__ table, int S,
-                                                          const unsigned char* __restrict__ rows,
-                                                          const double* __restrict__ phi,
-                                                          const double* __restrict__ temp, const double* __restrict__ z,
-                                                          const double* __restrict__ p_init, int64_t n,
-                                                          double* __restrict__ p_out, double* __restrict__ rho4,
-                                                          uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
-    extern __shared__ double lds[];
-    GcTable tb = stage_table(table, S, lds);
-    double* bonds = lds + gc_table_doubles(S);  // [2][16][GBLOCK]: dab then cnt
-    const int64_t i = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
-    if (i >= n) return;
-    GcModelT<double> m;
-    m.c.bond_dab = bonds + threadIdx.x;
-    m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
-    m.c.stride = GBLOCK;
-    const double T = temp[i];
-    gc_coef<double>(m.c, rows + (size_t)i * GC_ROW_BYTES, tb, phi[2 * i], phi[2 * i + 1], T);
-    MixResult r;
-    bool ok = bubble_dew_solve<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
+__device__ __forceinline__ void gc_store(int64_t i, int rc, const MixResult& r, double T, double* __restrict__ p_out,
+                                         double* __restrict__ rho4, uint8_t* __restrict__ status,
+                                         int32_t* __restrict__ iters) {
+    const bool ok = rc == BD_OK;
     if (p_out) p_out[i] = ok ? r.p * T * P_UNIT : 0.0;
     if (rho4) {
         double v0 = DEW ? r.spec0 : r.inc0, v1 = DEW ? r.spec1 : r.inc1;
@@ -68,6 +55,46 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
     }
     if (iters) iters[i] = ok ? r.iters : -1;
     status[i] = ok ? 0 : 1;
+}
+
+// K7.  RETRY = false: fast pass over all rows (small caps, cap hits appended to the retry list;
+// retry == nullptr -> full caps, single pass).  RETRY = true: robust pass, grid-stride over the list.
+template <bool DEW, bool RETRY>
+__global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restrict__ table, int S,
+                                                          const unsigned char* __restrict__ rows,
+                                                          const double* __restrict__ phi,
+                                                          const double* __restrict__ temp, const double* __restrict__ z,
+                                                          const double* __restrict__ p_init, int64_t n,
+                                                          double* __restrict__ p_out, double* __restrict__ rho4,
+                                                          uint8_t* __restrict__ status, int32_t* __restrict__ iters,
+                                                          int32_t* __restrict__ retry) {
+    extern __shared__ double lds[];
+    if (RETRY && (int64_t)blockIdx.x * GBLOCK >= (int64_t)retry[0]) return;  // whole workgroup idle: skip the staging
+    GcTable tb = stage_table(table, S, lds);
+    double* bonds = lds + gc_table_doubles(S);  // [2][16][GBLOCK]: dab then cnt
+    GcModelT<double> m;
+    m.c.bond_dab = bonds + threadIdx.x;
+    m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
+    m.c.stride = GBLOCK;
+    const int64_t first = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
+    const int64_t total = RETRY ? (int64_t)retry[0] : n;
+    const int64_t stride = RETRY ? (int64_t)gridDim.x * GBLOCK : total;  // fast pass: one row per lane
+    for (int64_t k = first; k < total; k += stride) {
+        const int64_t i = RETRY ? (int64_t)retry[1 + k] : k;
+        const double T = temp[i];
+        gc_coef<double>(m.c, rows + (size_t)i * GC_ROW_BYTES, tb, phi[2 * i], phi[2 * i + 1], T);
+        MixResult r;
+        const double p_red = p_init[i] / (T * P_UNIT);
+        int rc = (!RETRY && retry) ? bubble_dew_solve<DEW>(m, z[i], p_red, r, GC_FAST_SS, GC_FAST_NEWTON)
+                                   : bubble_dew_solve<DEW>(m, z[i], p_red, r);
+        if (!RETRY && rc == BD_CAP) {
+            status[i] = 1;  // provisional
+            retry[1 + atomicAdd(&retry[0], 1)] = (int32_t)i;
+        } else {
+            gc_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
+        }
+        if (!RETRY) break;
+    }
 }
 
 // GcPcSaftMix.derivatives (feos_torch/gc_pcsaft.py:443-468)
@@ -223,7 +250,7 @@ int64_t pcs_gc_table_doubles(int S) { return (int64_t)S * 8 + 3 * (int64_t)S * S
 
 int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
                       const double* z, const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status,
-                      int32_t* iters, void* stream) {
+                      int32_t* iters, void* workspace, void* stream) {
     g_err[0] = 0;
     if (int e = gc_check(S, n)) return e;
     if (n == 0) return 0;
@@ -231,12 +258,24 @@ int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, 
     const unsigned grid = (unsigned)((n + GBLOCK - 1) / GBLOCK);
     const size_t lds = gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE);
     hipStream_t s = as_stream(stream);
-    if (dew)
-        hipLaunchKernelGGL(k_gc_bubble_dew<true>, dim3(grid), dim3(GBLOCK), lds, s, table, S, rows, phi, temp, z, p_init, n, p_out,
-                           rho4, status, iters);
-    else
-        hipLaunchKernelGGL(k_gc_bubble_dew<false>, dim3(grid), dim3(GBLOCK), lds, s, table, S, rows, phi, temp, z, p_init, n,
-                           p_out, rho4, status, iters);
+    int32_t* retry = static_cast<int32_t*>(workspace);
+    if (retry) {
+        hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);
+        if (e != hipSuccess) return fail("hipMemsetAsync", e);
+    }
+    if (dew) {
+        hipLaunchKernelGGL((k_gc_bubble_dew<true, false>), dim3(grid), dim3(GBLOCK), lds, s, table, S, rows, phi, temp, z, p_init,
+                           n, p_out, rho4, status, iters, retry);
+        if (retry)
+            hipLaunchKernelGGL((k_gc_bubble_dew<true, true>), dim3(GC_RETRY_BLOCKS), dim3(GBLOCK), lds, s, table, S, rows, phi,
+                               temp, z, p_init, n, p_out, rho4, status, iters, retry);
+    } else {
+        hipLaunchKernelGGL((k_gc_bubble_dew<false, false>), dim3(grid), dim3(GBLOCK), lds, s, table, S, rows, phi, temp, z,
+                           p_init, n, p_out, rho4, status, iters, retry);
+        if (retry)
+            hipLaunchKernelGGL((k_gc_bubble_dew<false, true>), dim3(GC_RETRY_BLOCKS), dim3(GBLOCK), lds, s, table, S, rows, phi,
+                               temp, z, p_init, n, p_out, rho4, status, iters, retry);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_gc_bubble_dew launch", e);
     return 0;

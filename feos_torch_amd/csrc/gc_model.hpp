@@ -248,7 +248,8 @@ PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
                     n0 = 1.0 / (1.0 + x0 * e00 + x1 * e01);
                     n1 = 1.0 / (1.0 + x0 * e10 + x1 * e11);
                 }
-                bool conv = fabs(n0 - x0) <= 1e-15 * x0 && fabs(n1 - x1) <= 1e-15 * x1;
+                // 1e-12 is enough: the two Newton updates in R arithmetic below square the remaining error
+                bool conv = fabs(n0 - x0) <= 1e-12 * x0 && fabs(n1 - x1) <= 1e-12 * x1;
                 x0 = n0;
                 x1 = n1;
                 if (conv) break;
@@ -272,7 +273,7 @@ PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
                 if (f < 0.0) lo = x; else hi = x;
                 double n = x - s;
                 if (!(n >= lo && n <= hi && n > 0.0)) n = 0.5 * (lo + hi);
-                bool conv = fabs(n - x) <= 1e-15 * x;
+                bool conv = fabs(n - x) <= 1e-12 * x;
                 x = n;
                 if (conv) break;
             }

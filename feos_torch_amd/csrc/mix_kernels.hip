@@ -40,6 +40,27 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
     k1 = kk.y;
 }
 
+constexpr int FAST_SS = 12, FAST_NEWTON = 10;  // iteration caps of the fast pass (see mix_solver.hpp)
+constexpr int MIX_RETRY_GRID = 2048;             // 64-thread workgroups of the robust pass
+
+template <bool DEW>
+__device__ __forceinline__ void mix_store(int64_t i, int rc, const MixResult& r, double T, double* __restrict__ p_out,
+                                          double* __restrict__ rho4, uint8_t* __restrict__ status,
+                                          int32_t* __restrict__ iters) {
+    const bool ok = rc == BD_OK;
+    if (p_out) p_out[i] = ok ? r.p * T * P_UNIT : 0.0;
+    if (rho4) {
+        // reference layout (src/pcsaft.rs:225-228): [rhoV_1, rhoV_2, rhoL_1, rhoL_2]
+        double v0 = DEW ? r.spec0 : r.inc0, v1 = DEW ? r.spec1 : r.inc1;
+        double l0 = DEW ? r.inc0 : r.spec0, l1 = DEW ? r.inc1 : r.spec1;
+        reinterpret_cast<double4*>(rho4)[i] = ok ? make_double4(v0, v1, l0, l1) : make_double4(0.0, 0.0, 0.0, 0.0);
+    }
+    if (iters) iters[i] = ok ? r.iters : -1;
+    status[i] = ok ? 0 : 1;
+}
+
+// K5 fast pass: small iteration caps; rows that hit a cap go to the retry list (retry[0] = count).
+// retry == nullptr: single pass with the full caps.
 template <bool DEW>
 __global__ __launch_bounds__(MBLOCK) void k_mix_bubble_dew(const double* __restrict__ params,
                                                            const double* __restrict__ kij,
@@ -47,7 +68,8 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_bubble_dew(const double* __restr
                                                            const double* __restrict__ z,
                                                            const double* __restrict__ p_init, int64_t n,
                                                            double* __restrict__ p_out, double* __restrict__ rho4,
-                                                           uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
+                                                           uint8_t* __restrict__ status, int32_t* __restrict__ iters,
+                                                           int32_t* __restrict__ retry) {
     const int64_t i = (int64_t)blockIdx.x * MBLOCK + threadIdx.x;
     if (i >= n) return;
     double par[16], k0, k1;
@@ -57,17 +79,37 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_bubble_dew(const double* __restr
     mix_coef<double>(m.c, par, k0, k1, T);
     MixResult r;
     const double p_red = p_init[i] / (T * P_UNIT);
-    bool ok = bubble_dew_solve<DEW>(m, z[i], p_red, r);
-    if (p_out) p_out[i] = ok ? r.p * T * P_UNIT : 0.0;
-    if (rho4) {
-        // reference layout (src/pcsaft.rs:225-228): [rhoV_1, rhoV_2, rhoL_1, rhoL_2]
-        double v0 = DEW ? r.spec0 : r.inc0, v1 = DEW ? r.spec1 : r.inc1;
-        double l0 = DEW ? r.inc0 : r.spec0, l1 = DEW ? r.inc1 : r.spec1;
-        double4 o = ok ? make_double4(v0, v1, l0, l1) : make_double4(0.0, 0.0, 0.0, 0.0);
-        reinterpret_cast<double4*>(rho4)[i] = o;
+    int rc = retry ? bubble_dew_solve<DEW>(m, z[i], p_red, r, FAST_SS, FAST_NEWTON) : bubble_dew_solve<DEW>(m, z[i], p_red, r);
+    if (rc == BD_CAP) {
+        status[i] = 1;  // provisional
+        retry[1 + atomicAdd(&retry[0], 1)] = (int32_t)i;
+        return;
     }
-    if (iters) iters[i] = ok ? r.iters : -1;
-    status[i] = ok ? 0 : 1;
+    mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
+}
+
+// K5 robust pass over the compacted list: same arithmetic, full caps (count read on the device)
+template <bool DEW>
+__global__ __launch_bounds__(64) void k_mix_bubble_dew_retry(const double* __restrict__ params,
+                                                             const double* __restrict__ kij,
+                                                             const double* __restrict__ temp,
+                                                             const double* __restrict__ z,
+                                                             const double* __restrict__ p_init,
+                                                             double* __restrict__ p_out, double* __restrict__ rho4,
+                                                             uint8_t* __restrict__ status, int32_t* __restrict__ iters,
+                                                             const int32_t* __restrict__ retry) {
+    const int count = retry[0];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const int64_t i = retry[1 + k];
+        double par[16], k0, k1;
+        load_mix_row(params, kij, i, par, k0, k1);
+        const double T = temp[i];
+        MixModel m;
+        mix_coef<double>(m.c, par, k0, k1, T);
+        MixResult r;
+        int rc = bubble_dew_solve<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
+        mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
+    }
 }
 
 // PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420): a, p, mu_i, v_i at given partial densities
@@ -119,19 +161,31 @@ extern "C" {
 
 int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const double* temp, const double* z,
                        const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status, int32_t* iters,
-                       void* stream) {
+                       void* workspace, void* stream) {
     g_err[0] = 0;
     if (int e = check_n(n)) return e;
     if (n == 0) return 0;
     if (!params || !kij || !temp || !z || !p_init || !status) return fail_msg("pcs_mix_bubble_dew: null required pointer");
     const unsigned grid = (unsigned)((n + MBLOCK - 1) / MBLOCK);
     hipStream_t s = as_stream(stream);
-    if (dew)
+    int32_t* retry = static_cast<int32_t*>(workspace);
+    if (retry) {
+        hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);
+        if (e != hipSuccess) return fail("hipMemsetAsync", e);
+    }
+    if (dew) {
         hipLaunchKernelGGL(k_mix_bubble_dew<true>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
-                           rho4, status, iters);
-    else
+                           rho4, status, iters, retry);
+        if (retry)
+            hipLaunchKernelGGL(k_mix_bubble_dew_retry<true>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
+                               p_out, rho4, status, iters, (const int32_t*)retry);
+    } else {
         hipLaunchKernelGGL(k_mix_bubble_dew<false>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
-                           rho4, status, iters);
+                           rho4, status, iters, retry);
+        if (retry)
+            hipLaunchKernelGGL(k_mix_bubble_dew_retry<false>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
+                               p_out, rho4, status, iters, (const int32_t*)retry);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_mix_bubble_dew launch", e);
     return 0;

@@ -50,23 +50,36 @@ PCS_DEV void line_eval(const Model& m, double x0, double x1, double rho, double&
     dp = 1.0 + rho * r.d2;
 }
 
-// liquid-like root of p(rho) = p_spec at composition x from the dense side
+constexpr int LIQ_ROOT_MAX_IT = 30;  // Newton from the dense side needs ~5-10; a row that needs more fails
+
+// liquid-like root of p(rho) = p_spec at composition x.  Cold start: Newton from the dense side
+// (eta = 0.5, monotone on the convex branch).  rho_start > 0: warm start from a previous root at a
+// nearby composition (successive substitution), falling back to the cold start if it misbehaves.
 template <class Model>
-PCS_DEV bool liquid_root(const Model& m, double x0, double x1, double p_spec, double& rho_out) {
+PCS_DEV bool liquid_root(const Model& m, double x0, double x1, double p_spec, double& rho_out, double rho_start = 0.0) {
     double pk = m.packing(x0, x1);
-    double rho = 0.5 / pk;
+    bool warm = rho_start > 0.0;
+    double rho = warm ? rho_start : 0.5 / pk;
     double err_prev = 1.0;
-    for (int it = 0; it < 60; it++) {
+    for (int it = 0; it < LIQ_ROOT_MAX_IT; it++) {
         double p, dp, a;
         line_eval(m, x0, x1, rho, p, dp, a);
-        if (it == 0 && !(p > p_spec)) {
+        if (!warm && it == 0 && !(p > p_spec)) {
             rho = 0.62 / pk;
             line_eval(m, x0, x1, rho, p, dp, a);
         }
-        if (!(dp > 0.0) || !is_finite_bits(p)) return false;
+        bool bad = !(dp > 0.0) || !is_finite_bits(p);
         double step = (p - p_spec) / dp;
         double rho_new = rho - step;
-        if (!(rho_new > 0.0) || !is_finite_bits(rho_new)) return false;
+        bad = bad || !(rho_new > 0.0) || !is_finite_bits(rho_new) || (warm && !(rho_new * pk < 0.7));
+        if (bad) {
+            if (!warm) return false;
+            warm = false;  // restart cold
+            rho = 0.5 / pk;
+            err_prev = 1.0;
+            it = -1;
+            continue;
+        }
         double err = fabs(step) / rho;
         bool done = err <= 1e-10 || (it >= 3 && err < 1e-7 && err >= 0.25 * err_prev);
         err_prev = err;
@@ -105,6 +118,13 @@ PCS_DEV bool solve3(double A[3][4], double* x) {
     return true;
 }
 
+// Iteration caps.  The kernels are latency-bound by their slowest lane, so the caps matter: converged
+// rows need <= 31 (bubble) / <= 25 at the 99.9th percentile (dew) Newton iterations on the synthetic
+// workload; rows that need more are reported as failed (status 1), as are successive-substitution
+// runs that have not settled after SS_MAX_IT sweeps.  The CPU oracle uses the same caps.
+constexpr int SS_MAX_IT = 40;
+constexpr int NEWTON_MAX_IT = 60;
+
 struct MixResult {
     double spec0, spec1, inc0, inc1;  // converged partial densities
     double p;                         // reduced pressure from the reference's final formula
@@ -124,13 +144,20 @@ PCS_DEV double bubble_dew_formula(const PhaseEval& s, const PhaseEval& n) {
     return -(n.a / rho_i + s.p() * v + g - 1.0) / (1.0 / rho_i - v);
 }
 
+// Return codes of bubble_dew_solve
+enum : int { BD_OK = 0, BD_FAILED = 1, BD_CAP = 2 };
+
+// ss_max / newton_max: iteration caps of this call.  BD_CAP = a cap was hit before the iteration
+// settled: with the full caps that is a failure; the fast pass of the kernels uses small caps and
+// hands BD_CAP rows to the robust pass, which repeats the identical arithmetic with the full caps.
 template <bool DEW, class Model>
-PCS_DEV bool bubble_dew_solve(const Model& m, double z0, double p_init, MixResult& out) {
+PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
+                             int newton_max = NEWTON_MAX_IT) {
     const double z1 = 1.0 - z0;
     double rs, ri0, ri1;
     out.iters = 0;
     if (!DEW) {
-        if (!liquid_root(m, z0, z1, p_init, rs) && !liquid_root(m, z0, z1, 0.0, rs)) return false;
+        if (!liquid_root(m, z0, z1, p_init, rs) && !liquid_root(m, z0, z1, 0.0, rs)) return BD_FAILED;
         PhaseEval e = phase_eval(m, z0 * rs, z1 * rs);
         ri0 = e.r0 * exp(e.g0);
         ri1 = e.r1 * exp(e.g1);
@@ -155,8 +182,9 @@ PCS_DEV bool bubble_dew_solve(const Model& m, double z0, double p_init, MixResul
             x1 = z1;
         }
         double rl = 0.0;
-        for (int ss = 0; ss < 200; ss++) {
-            if (!liquid_root(m, x0, x1, 0.0, rl) && !liquid_root(m, x0, x1, p0, rl)) return false;
+        bool settled = false;
+        for (int ss = 0; ss < ss_max; ss++) {
+            if (!liquid_root(m, x0, x1, 0.0, rl, rl) && !liquid_root(m, x0, x1, p0, rl)) return BD_FAILED;
             PhaseEval e = phase_eval(m, x0 * rl, x1 * rl);
             double w0 = z0 * x0 / (e.r0 * exp(e.g0)), w1 = z1 * x1 / (e.r1 * exp(e.g1));
             double sum = w0 + w1;
@@ -168,15 +196,16 @@ PCS_DEV bool bubble_dew_solve(const Model& m, double z0, double p_init, MixResul
             x0 = n0 / s2;
             x1 = n1 / s2;
             p0 = 1.0 / sum;
-            if (dx < 1e-7) break;
+            if (dx < 1e-7) { settled = true; break; }
         }
-        if (!liquid_root(m, x0, x1, p0, rl) && !liquid_root(m, x0, x1, 0.0, rl)) return false;
+        if (!settled && ss_max < SS_MAX_IT) return BD_CAP;
+        if (!liquid_root(m, x0, x1, p0, rl) && !liquid_root(m, x0, x1, 0.0, rl)) return BD_FAILED;
         ri0 = x0 * rl;
         ri1 = x1 * rl;
         rs = p0;
     }
     double err_prev = 1.0;
-    for (int it = 0; it < 200; it++) {
+    for (int it = 0; it < newton_max; it++) {
         PhaseEval s = phase_eval(m, z0 * rs, z1 * rs);
         PhaseEval n = phase_eval(m, ri0, ri1);
         double A[3][4];
@@ -194,9 +223,9 @@ PCS_DEV bool bubble_dew_solve(const Model& m, double z0, double p_init, MixResul
         A[1][3] = -(s.mu1() - n.mu1());
         A[2][3] = -(s.p() - n.p());
         double du[3];
-        if (!solve3(A, du)) return false;
+        if (!solve3(A, du)) return BD_FAILED;
         double mx = fmax(fabs(du[0]), fmax(fabs(du[1]), fabs(du[2])));
-        if (!is_finite_bits(mx)) return false;
+        if (!is_finite_bits(mx)) return BD_FAILED;
         double scale = mx > 1.0 ? 1.0 / mx : 1.0;  // at most a factor e per iteration
         rs *= exp(scale * du[0]);
         ri0 *= exp(scale * du[1]);
@@ -207,16 +236,16 @@ PCS_DEV bool bubble_dew_solve(const Model& m, double z0, double p_init, MixResul
         if (mx <= 1e-9 || stagnated) {
             double dens_i = ri0 + ri1;
             double lo = DEW ? rs : dens_i, hi = DEW ? dens_i : rs;
-            if (!(lo < hi * (1.0 - 1e-6))) return false;  // trivial solution
+            if (!(lo < hi * (1.0 - 1e-6))) return BD_FAILED;  // trivial solution
             // final evaluation at the converged state -> reference formula
             PhaseEval sf = phase_eval(m, z0 * rs, z1 * rs);
             PhaseEval nf = phase_eval(m, ri0, ri1);
             out.spec0 = sf.r0; out.spec1 = sf.r1; out.inc0 = ri0; out.inc1 = ri1;
             out.p = bubble_dew_formula(sf, nf);
-            return is_finite_bits(out.p);
+            return is_finite_bits(out.p) ? BD_OK : BD_FAILED;
         }
     }
-    return false;
+    return (newton_max < NEWTON_MAX_IT) ? BD_CAP : BD_FAILED;
 }
 
 }  // namespace pcs

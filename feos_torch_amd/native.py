@@ -212,9 +212,10 @@ def mix_bubble_dew(params, kij, temperature, molefracs, pressure, dew, want_iter
         rho4 = torch.empty((n, 4), dtype=_F64, device=device)
         status = torch.empty(n, dtype=torch.uint8, device=device)
         iters = torch.empty(n, dtype=torch.int32, device=device) if want_iters else None
+        ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
         rc = L.pcs_mix_bubble_dew(int(bool(dew)), _lib.ptr(params), _lib.ptr(kij), _lib.ptr(temperature),
                                   _lib.ptr(molefracs), _lib.ptr(pressure), n, _lib.ptr(p), _lib.ptr(rho4),
-                                  _lib.ptr(status), _lib.ptr(iters), _lib.current_stream_ptr(device))
+                                  _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws), _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_mix_bubble_dew")
     return {"p": p, "rho4": rho4, "status": status.bool(), "iters": iters}
 
@@ -297,9 +298,11 @@ def gc_bubble_dew(table, S, rows, phi, temperature, molefracs, pressure, dew, wa
         rho4 = torch.empty((n, 4), dtype=_F64, device=device)
         status = torch.empty(n, dtype=torch.uint8, device=device)
         iters = torch.empty(n, dtype=torch.int32, device=device) if want_iters else None
+        ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
         rc = L.pcs_gc_bubble_dew(int(bool(dew)), _lib.ptr(table), int(S), _lib.ptr(rows), _lib.ptr(phi),
                                  _lib.ptr(temperature), _lib.ptr(molefracs), _lib.ptr(pressure), n, _lib.ptr(p),
-                                 _lib.ptr(rho4), _lib.ptr(status), _lib.ptr(iters), _lib.current_stream_ptr(device))
+                                 _lib.ptr(rho4), _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws),
+                                 _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_gc_bubble_dew")
     return {"p": p, "rho4": rho4, "status": status.bool(), "iters": iters}
 

@@ -113,10 +113,13 @@ int pcs_pure_jacobian(int which, const double* params, const double* temp, const
  *   rho4    [n,4]   out   A^-3 (rhoV_1, rhoV_2, rhoL_1, rhoL_2), src/pcsaft.rs:225-228 (optional)
  *   status  [n]     out   uint8, 1 = failed
  *   iters   [n]     out   int32 Newton iterations (optional)
+ *   workspace       device scratch of pcs_workspace_bytes(n) for the two-pass schedule (fast pass with
+ *                   small iteration caps + robust pass over the compacted slow rows); NULL = one pass
+ *                   with the full caps (same results, slower)
  */
 int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const double* temp, const double* z,
                        const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status, int32_t* iters,
-                       void* stream);
+                       void* workspace, void* stream);
 
 /*
  * PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420) at given partial densities rho [n,2]:
@@ -148,12 +151,12 @@ int pcs_mix_jacobian(int dew, const double* params, const double* kij, const dou
  *                             bond_cnt [64:80] (count 0 = unused entry)
  *   phi    [n,2]         in   src/gc_pcsaft.rs:30, feos_torch/gc_pcsaft.py:182-185
  *   temp, z, p_init [n]  in   as for pcs_mix_bubble_dew
- *   outputs                   as for pcs_mix_bubble_dew
+ *   outputs, workspace        as for pcs_mix_bubble_dew
  */
 int64_t pcs_gc_table_doubles(int S);
 int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
                       const double* z, const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status,
-                      int32_t* iters, void* stream);
+                      int32_t* iters, void* workspace, void* stream);
 
 /* GcPcSaftMix.derivatives (feos_torch/gc_pcsaft.py:443-468): a, p, mu [n,2], v [n,2] at rho [n,2]. */
 int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,

@@ -65,7 +65,7 @@ template <class F, class Model>
 bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out) {
     F rho = F(0.5) / model.packing(T, x);
     F err_prev = F(1);
-    for (int it = 0; it < 200; it++) {
+    for (int it = 0; it < 30; it++) {  // same cap as the kernels
         F r[2] = {x[0] * rho, x[1] * rho};
         PhaseEval<F> e = eval_phase<F>(model, T, r);
         F p = e.p(), dp = x[0] * e.dp(0) + x[1] * e.dp(1);
@@ -147,7 +147,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         //   x_i <- (y_i x_i / f_i) / sum_j (y_j x_j / f_j),   p = 1 / sum_j (y_j x_j / f_j)
         F rl = 0;
         bool have = false;
-        for (int ss = 0; ss < 200; ss++) {
+        for (int ss = 0; ss < 40; ss++) {  // same caps as the kernels (csrc/mix_solver.hpp)
             if (!liquid_root<F>(model, T, x, F(0), rl)) {
                 if (!liquid_root<F>(model, T, x, p0, rl)) return false;
             }
@@ -179,7 +179,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
     }
     // Newton in (ln rho_spec, ln rho_inc_1, ln rho_inc_2)
     F err_prev = F(1);
-    for (int it = 0; it < 200; it++) {
+    for (int it = 0; it < 60; it++) {
         F r_s[2] = {z[0] * rs, z[1] * rs};
         PhaseEval<F> s = eval_phase<F>(model, T, r_s);
         PhaseEval<F> n = eval_phase<F>(model, T, ri);

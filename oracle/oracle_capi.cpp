@@ -266,8 +266,8 @@ namespace {
 
 template <class S, class F>
 S lift_to(const F& x) { S s(0.0); s.re = x; return s; }
-template <> double lift_to<double, double>(const double& x) { return x; }
-template <> long double lift_to<long double, long double>(const long double& x) { return x; }
+template <> [[maybe_unused]] double lift_to<double, double>(const double& x) { return x; }
+template <> [[maybe_unused]] long double lift_to<long double, long double>(const long double& x) { return x; }
 
 template <class S, class F>
 MixParams<S> lift_mix(const MixParams<F>& q) {
