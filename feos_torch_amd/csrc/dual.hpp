@@ -4,7 +4,9 @@
 //   D2<T>      value + 1st + 2nd derivative along ONE direction     (Dual3, dual.py:5-78)
 //   DN<T,N>    value + N first derivatives                          (parameter tangents; what
 //              torch reverse mode delivers in the reference is delivered forward here)
-//   HD<T,N>    value, eps1[N], eps2, eps1eps2[N]                     (DualTensor, dual_torch.py:4-158)
+//   T2<T>      value, gradient and Hessian in the two partial densities (supersedes DualTensor,
+//              dual_torch.py:4-158, which carries only the volume-mixed second derivatives)
+//   T1<T>      value and gradient in the two partial densities (with T = DN: parameter tangents)
 // All are plain aggregates living in VGPRs; every loop over N is fully unrolled.  The types
 // nest (D2<DN<double,3>> = d/drho, d2/drho2 and their parameter tangents) and mix with plain
 // double on either side so model code is written once (pure_model.hpp, mix_model.hpp).
@@ -145,83 +147,6 @@ template <class T, int N> PCS_DEV DN<T, N> d_sqrt(const DN<T, N>& a) { T s = d_s
 template <class T, int N> PCS_DEV DN<T, N> d_cbrt(const DN<T, N>& a) { T s = d_cbrt(a.v); return a.chain(s, s * d_recip(a.v) * (1.0 / 3.0)); }
 
 // =========================================================================================
-// HD<T,N>: hyper-dual with N "eps1" directions and one "eps2" direction
-// =========================================================================================
-template <class T, int N>
-struct HD {
-    T v;
-    T e1[N];
-    T e2;
-    T e12[N];
-    PCS_DEV HD() {}
-    PCS_DEV HD(double x) : v(x), e2(0.0) {
-#pragma unroll
-        for (int i = 0; i < N; i++) { e1[i] = T(0.0); e12[i] = T(0.0); }
-    }
-    PCS_DEV HD chain(const T& f0, const T& f1, const T& f2) const {
-        HD r;
-        r.v = f0;
-        r.e2 = f1 * e2;
-        T f2e2 = f2 * e2;
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            r.e1[i] = f1 * e1[i];
-            r.e12[i] = f1 * e12[i] + f2e2 * e1[i];
-        }
-        return r;
-    }
-};
-template <class T, int N> struct is_dual<HD<T, N>> { static constexpr bool value = true; };
-template <class T, int N> PCS_DEV double re(const HD<T, N>& a) { return re(a.v); }
-template <class T, int N> PCS_DEV HD<T, N> operator+(const HD<T, N>& a, const HD<T, N>& b) {
-    HD<T, N> r; r.v = a.v + b.v; r.e2 = a.e2 + b.e2;
-    PCS_DN_LOOP { r.e1[i] = a.e1[i] + b.e1[i]; r.e12[i] = a.e12[i] + b.e12[i]; }
-    return r;
-}
-template <class T, int N> PCS_DEV HD<T, N> operator-(const HD<T, N>& a, const HD<T, N>& b) {
-    HD<T, N> r; r.v = a.v - b.v; r.e2 = a.e2 - b.e2;
-    PCS_DN_LOOP { r.e1[i] = a.e1[i] - b.e1[i]; r.e12[i] = a.e12[i] - b.e12[i]; }
-    return r;
-}
-template <class T, int N> PCS_DEV HD<T, N> operator-(const HD<T, N>& a) {
-    HD<T, N> r; r.v = -a.v; r.e2 = -a.e2;
-    PCS_DN_LOOP { r.e1[i] = -a.e1[i]; r.e12[i] = -a.e12[i]; }
-    return r;
-}
-template <class T, int N> PCS_DEV HD<T, N> operator*(const HD<T, N>& a, const HD<T, N>& b) {
-    HD<T, N> r; r.v = a.v * b.v; r.e2 = a.v * b.e2 + b.v * a.e2;
-    PCS_DN_LOOP {
-        r.e1[i] = a.v * b.e1[i] + b.v * a.e1[i];
-        r.e12[i] = a.v * b.e12[i] + a.e1[i] * b.e2 + a.e2 * b.e1[i] + a.e12[i] * b.v;
-    }
-    return r;
-}
-template <class T, int N> PCS_DEV HD<T, N> operator+(const HD<T, N>& a, double b) { HD<T, N> r = a; r.v = a.v + b; return r; }
-template <class T, int N> PCS_DEV HD<T, N> operator+(double b, const HD<T, N>& a) { HD<T, N> r = a; r.v = a.v + b; return r; }
-template <class T, int N> PCS_DEV HD<T, N> operator-(const HD<T, N>& a, double b) { HD<T, N> r = a; r.v = a.v - b; return r; }
-template <class T, int N> PCS_DEV HD<T, N> operator-(double b, const HD<T, N>& a) { HD<T, N> r = -a; r.v = b - a.v; return r; }
-template <class T, int N> PCS_DEV HD<T, N> operator*(const HD<T, N>& a, double b) {
-    HD<T, N> r; r.v = a.v * b; r.e2 = a.e2 * b;
-    PCS_DN_LOOP { r.e1[i] = a.e1[i] * b; r.e12[i] = a.e12[i] * b; }
-    return r;
-}
-template <class T, int N> PCS_DEV HD<T, N> operator*(double b, const HD<T, N>& a) { return a * b; }
-template <class T, int N> PCS_DEV HD<T, N> d_recip(const HD<T, N>& a) { T r = d_recip(a.v); T r2 = r * r; return a.chain(r, -r2, 2.0 * (r2 * r)); }
-template <class T, int N> PCS_DEV HD<T, N> operator/(const HD<T, N>& a, const HD<T, N>& b) { return a * d_recip(b); }
-template <class T, int N> PCS_DEV HD<T, N> operator/(const HD<T, N>& a, double b) { double r = 1.0 / b; return a * r; }
-template <class T, int N> PCS_DEV HD<T, N> operator/(double b, const HD<T, N>& a) { return d_recip(a) * b; }
-template <class T, int N> PCS_DEV HD<T, N> d_log(const HD<T, N>& a) { T r = d_recip(a.v); return a.chain(d_log(a.v), r, -(r * r)); }
-template <class T, int N> PCS_DEV HD<T, N> d_exp(const HD<T, N>& a) { T e = d_exp(a.v); return a.chain(e, e, e); }
-template <class T, int N> PCS_DEV HD<T, N> d_sqrt(const HD<T, N>& a) {
-    T s = d_sqrt(a.v); T h = 0.5 * d_recip(s);
-    return a.chain(s, h, -(h * d_recip(a.v)) * 0.5);
-}
-template <class T, int N> PCS_DEV HD<T, N> d_cbrt(const HD<T, N>& a) {
-    T s = d_cbrt(a.v); T rx = d_recip(a.v); T f1 = s * rx * (1.0 / 3.0);
-    return a.chain(s, f1, f1 * rx * (-2.0 / 3.0));
-}
-
-// =========================================================================================
 // T2<T>: second-order Taylor coefficients in TWO variables (the partial densities rho_1, rho_2):
 //        v, g[2] = d/drho_i, h[3] = d2/drho_1^2, d2/drho_1 drho_2, d2/drho_2^2.
 // Carries everything the bubble/dew Newton needs (chemical potentials, pressure and their full
@@ -320,6 +245,5 @@ template <class T> struct Lift<D2<T>, double> { static PCS_DEV D2<T> go(double p
 template <class T, int N> struct Lift<DN<T, N>, double> { static PCS_DEV DN<T, N> go(double p) { return DN<T, N>(p); } };
 template <class T> struct Lift<T1<T>, T> { static PCS_DEV T1<T> go(const T& p) { return T1<T>(p, T(0.0), T(0.0)); } };
 template <class T> struct Lift<T2<T>, double> { static PCS_DEV T2<T> go(double p) { return T2<T>(p); } };
-template <class T, int N> struct Lift<HD<T, N>, double> { static PCS_DEV HD<T, N> go(double p) { return HD<T, N>(p); } };
 
 }  // namespace pcs

@@ -61,8 +61,11 @@ __device__ __forceinline__ void mix_store(int64_t i, int rc, const MixResult& r,
 
 // K5 fast pass: small iteration caps; rows that hit a cap go to the retry list (retry[0] = count).
 // retry == nullptr: single pass with the full caps.
+#ifndef MIX_WAVES
+#define MIX_WAVES 2  // min waves per SIMD (A/B: 1..4 within 10 %, 2 fastest)
+#endif
 template <bool DEW>
-__global__ __launch_bounds__(MBLOCK) void k_mix_bubble_dew(const double* __restrict__ params,
+__global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const double* __restrict__ params,
                                                            const double* __restrict__ kij,
                                                            const double* __restrict__ temp,
                                                            const double* __restrict__ z,
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_bubble_dew(const double* __restr
 
 // K5 robust pass over the compacted list: same arithmetic, full caps (count read on the device)
 template <bool DEW>
-__global__ __launch_bounds__(64) void k_mix_bubble_dew_retry(const double* __restrict__ params,
+__global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const double* __restrict__ params,
                                                              const double* __restrict__ kij,
                                                              const double* __restrict__ temp,
                                                              const double* __restrict__ z,

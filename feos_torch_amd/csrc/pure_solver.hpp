@@ -18,12 +18,6 @@
 #include "pure_model.hpp"
 #include "pure_f32.hpp"
 
-#ifdef PCS_NO_NANPROOF
-#define PCS_NP(...)
-#else
-#define PCS_NP(...) __VA_ARGS__
-#endif
-
 namespace pcs {
 
 enum : int { ST_OK = 0, ST_FAILED = 1, ST_RETRY = 2 };
@@ -77,13 +71,13 @@ PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, 
                 rho = 0.62 / c.ceta;
                 e = pure_eval(c, rho);
             }
-            if (PCS_NP(!is_finite_bits(e.dp) ||) !(e.dp > 0.0) || !is_finite_bits(e.p)) {
+            if (!is_finite_bits(e.dp) || !(e.dp > 0.0) || !is_finite_bits(e.p)) {
                 fail = true;
             } else {
                 double step = (e.p - p_spec) / e.dp;
                 last = e;
                 double rho_new = rho - step;
-                if (PCS_NP(!is_finite_bits(rho_new) ||) !(rho_new > 0.0)) {
+                if (!is_finite_bits(rho_new) || !(rho_new > 0.0)) {
                     fail = true;
                 } else {
                     done = fabs(step) <= tol * rho;
@@ -159,21 +153,15 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = T
     }
     bool done = false;
     out.iters = 0;
-#ifdef PCS_DEBUG_CODES
-    if (!active) { out.iters = warm ? 20 : 10; out.rho_v = rv; out.rho_l = rl; }
-#endif
     for (int it = 0; it < VLE_MAX_IT; it++) {
         if (active && !done) {
             Eval v = pure_eval(c, rv);
             VleStep s = vle_step(l, v, rl, rv);
-            bool ok = PCS_NP(is_finite_bits(l.dp) && is_finite_bits(v.dp) &&) (l.dp > 0.0) && (v.dp > 0.0) && is_finite_bits(s.p_star) && is_finite_bits(s.dl) && is_finite_bits(s.dv);
+            bool ok = is_finite_bits(l.dp) && is_finite_bits(v.dp) && (l.dp > 0.0) && (v.dp > 0.0) && is_finite_bits(s.p_star) && is_finite_bits(s.dl) && is_finite_bits(s.dv);
             double rl_new = rl + s.dl, rv_new = rv + s.dv;
             ok = ok && (rl_new > 0.0) && (rv_new > 0.0) && (rv_new < rl_new);
             if (!ok) {
                 active = false;
-#ifdef PCS_DEBUG_CODES
-                out.iters = 100 + it + (warm ? 50 : 0); out.rho_v = rv; out.rho_l = rl;
-#endif
             } else {
                 done = (fabs(s.dl) <= tol_l * rl) && (fabs(s.dv) <= tol_v * rv);
                 rl = rl_new;

@@ -50,16 +50,21 @@ def _encode_molecule(segs, bonds, idx):
 def encode_rows(segment_identifier, segment_lists, bond_lists):
     """[N, 80] uint8 row encoding (layout of include/pcsaft_hip.h)."""
     idx = {s: i for i, s in enumerate(segment_identifier)}
-    cache = {}
+    cache, id_cache = {}, {}
     n = len(segment_lists)
     rows = np.zeros((n, 80), dtype=np.uint8)
     for r in range(n):
         for c in range(2):
-            key = (tuple(segment_lists[r][c]), tuple(map(tuple, bond_lists[r][c])))
-            enc = cache.get(key)
+            segs, bonds = segment_lists[r][c], bond_lists[r][c]
+            # batches usually re-use the same list objects for the same molecule: identity first
+            enc = id_cache.get((id(segs), id(bonds)))
             if enc is None:
-                enc = _encode_molecule(segment_lists[r][c], bond_lists[r][c], idx)
-                cache[key] = enc
+                key = (tuple(segs), tuple(map(tuple, bonds)))
+                enc = cache.get(key)
+                if enc is None:
+                    enc = _encode_molecule(segs, bonds, idx)
+                    cache[key] = enc
+                id_cache[(id(segs), id(bonds))] = enc
             rows[r, 8 * c:8 * c + 8] = enc[0:8]
             rows[r, 16 + 8 * c:16 + 8 * c + 8] = enc[8:16]
             rows[r, 32 + 8 * c:32 + 8 * c + 8] = enc[16:24]
