@@ -13,6 +13,11 @@
 
 namespace pcs {
 
+#ifndef PCS_F32_LIQ_TOL
+#define PCS_F32_LIQ_TOL 5e-2f  // relative step at which the fp32 liquid initialiser hands over to the coupled iteration
+// (A/B on 1e7 rows: 2e-4 3.56 ms, 2e-2 3.18 ms, 5e-2 3.11 ms, 1e-1 5.3 ms: the vapour estimate gets too poor)
+#endif
+
 struct F2 {  // value, d/drho, d2/drho2 in fp32
     float v, d1, d2;
 };
@@ -148,7 +153,7 @@ PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double&
                 float step = e.p / e.dp;
                 float rn = rl - step;
                 if (!(rn > 0.0f)) { ok = false; done = true; }
-                else { done = fabsf(step) <= 2e-4f * rl; rl = rn; }
+                else { done = fabsf(step) <= PCS_F32_LIQ_TOL * rl; rl = rn; }
             }
         }
         if (__ballot(!done) == 0ull) break;

@@ -60,7 +60,10 @@ __device__ __forceinline__ void stage_params(const double* __restrict__ params, 
 // K1: pure VLE, fast path.  Rows that need the robust initialisation are appended to
 // retry[1..]; retry[0] is the running count.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_pure_vle(const double* __restrict__ params,
+#ifndef K1_WAVES
+#define K1_WAVES 2
+#endif
+__global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __restrict__ params,
                                                     const double* __restrict__ temp, int64_t n,
                                                     double* __restrict__ p_sat, double* __restrict__ rho_eq,
                                                     double* __restrict__ rho_vl, uint8_t* __restrict__ status,
