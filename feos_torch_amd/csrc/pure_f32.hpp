@@ -13,9 +13,23 @@
 
 namespace pcs {
 
+#ifndef PCS_F32_PREDICT_STOP
+#define PCS_F32_PREDICT_STOP 1  // stop the fp32 iteration when the PREDICTED next step (quadratic convergence) is below the fp32 noise floor
+#endif
+#ifndef PCS_F32_PREDICT_TOL_L
+#define PCS_F32_PREDICT_TOL_L 5e-6f
+#endif
+#ifndef PCS_F32_PREDICT_TOL_V
+#define PCS_F32_PREDICT_TOL_V 5e-5f
+#endif
+#ifndef PCS_F32_PREDICT_CMAX
+#define PCS_F32_PREDICT_CMAX 1e3f
+#endif
+#ifndef PCS_F32_DENSE_RESTART
+#define PCS_F32_DENSE_RESTART 1
+#endif
 #ifndef PCS_F32_LIQ_TOL
-#define PCS_F32_LIQ_TOL 5e-2f  // relative step at which the fp32 liquid initialiser hands over to the coupled iteration
-// (A/B on 1e7 rows: 2e-4 3.56 ms, 2e-2 3.18 ms, 5e-2 3.11 ms, 1e-1 5.3 ms: the vapour estimate gets too poor)
+#define PCS_F32_LIQ_TOL 1e-1f  // relative (scaled-Newton) step at which the fp32 liquid initialiser hands over to the coupled iteration
 #endif
 
 struct F2 {  // value, d/drho, d2/drho2 in fp32
@@ -136,46 +150,81 @@ PCS_DEV bool finitef(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7
 
 // fp32 pass.  Returns true with (rl, rv) close to the solution (typically 1e-6 relative) when
 // every step of the pass behaved; false = this lane must use the fp64 initialiser.
-PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double& rv_out) {
+PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double& rv_out, int* diag = nullptr) {
+    int n_liq = 0, n_cpl = 0, code = 0;
     PureCoefF f;
     to_f32(c, f);
     bool ok = finitef(f.da) && finitef(f.kd2) && finitef(f.ceta) && f.ceta > 0.0f;
     // zero-pressure liquid, Newton from eta = 0.5 (monotone from the dense side)
     float rl = 0.5f / f.ceta;
-    bool done = !ok;
+    bool done = !ok, dense = false;
     for (int it = 0; it < 12; it++) {
         if (!done) {
             EvalF e = pure_eval_f32(f, rl);
-            if (!finitef(e.p) || !(e.dp > 0.0f) || (it == 0 && !(e.p > 0.0f))) {
+            n_liq++;
+            if (PCS_F32_DENSE_RESTART && it == 0 && finitef(e.p) && !(e.p > 0.0f)) {
+                // strongly attractive row (large dipole / association at low T): the zero-pressure liquid lies
+                // above eta = 0.5; restart on its dense side (plain Newton is monotone from there)
+                dense = true;
+                rl = 0.58f / f.ceta;
+            } else if (!finitef(e.p) || !(e.dp > 0.0f) || (it == (dense ? 1 : 0) && !(e.p > 0.0f))) {
                 ok = false;
                 done = true;
             } else {
+#ifdef PCS_LIQ_PLAIN_NEWTON
                 float step = e.p / e.dp;
+#else
+                // Newton on p (1-eta)^4 = 0 (same root): the hard-sphere pole makes p(rho) very steep on the
+                // dense side, the scaled function is close to linear -> 2-3 evaluations instead of 4-6
+                float den = dense ? e.dp : e.dp - 4.0f * e.p * f.ceta * __builtin_amdgcn_rcpf(1.0f - rl * f.ceta);
+                float step = e.p * __builtin_amdgcn_rcpf(den);
+                if (!(den > 0.0f)) step = 2.0f * rl;  // -> rn < 0 -> this lane takes the fp64 initialiser
+#endif
                 float rn = rl - step;
                 if (!(rn > 0.0f)) { ok = false; done = true; }
-                else { done = fabsf(step) <= PCS_F32_LIQ_TOL * rl; rl = rn; }
+                else { done = fabsf(step) <= (dense ? 1e-2f : PCS_F32_LIQ_TOL) * rl; rl = rn; }
             }
         }
         if (__ballot(!done) == 0ull) break;
     }
+#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 2  // timing experiments only
+    rl_out = (double)rl; rv_out = ok ? 1.0 : 2.0; return ok;
+#endif
     EvalF l = pure_eval_f32(f, rl);
     float rv = rl * __expf(l.mu);
+    if (diag) code = !ok ? 1 : !done ? 5 : !finitef(rv) ? 6 : !(l.dp > 0.0f) ? 7 : !(rv < 0.5f * rl) ? 8 : !(rv > 1e-30f) ? 9 : 0;
     ok = ok && done && finitef(rv) && (l.dp > 0.0f) && (rv < 0.5f * rl) && (rv > 1e-30f);
     // coupled Newton towards the equal-area pressure, to the fp32 noise floor
     done = !ok;
+#if PCS_F32_PREDICT_STOP
+    float sl_prev = 1.0f, sv_prev = 1.0f;
+#endif
     for (int it = 0; it < 8; it++) {
         if (!done) {
             EvalF v = pure_eval_f32(f, rv);
+            n_cpl++;
             float iv = __builtin_amdgcn_rcpf(rv), il = __builtin_amdgcn_rcpf(rl);
             float ps = -(v.a * iv - l.a * il + __logf(rv * il)) * __builtin_amdgcn_rcpf(iv - il);
             float dl = -(l.p - ps) * __builtin_amdgcn_rcpf(l.dp);
             float dv = -(v.p - ps) * __builtin_amdgcn_rcpf(v.dp);
             float rln = rl + dl, rvn = rv + dv;
+            // a large downward vapour step (poor first estimate at very low pressures) is taken in ln(rho) instead
+            if (rvn < 0.3f * rv) rvn = rv * __expf(dv * iv);
             if (!finitef(rln) || !finitef(rvn) || !(v.dp > 0.0f) || !(l.dp > 0.0f) || !(rvn > 1e-30f) || !(rvn < 0.6f * rln)) {
+                if (diag) code = (!finitef(rln) || !finitef(rvn)) ? 10 : !(v.dp > 0.0f) ? 11 : !(l.dp > 0.0f) ? 12 : !(rvn > 1e-30f) ? 13 : 14;
                 ok = false;
                 done = true;
             } else {
+#if PCS_F32_PREDICT_STOP
+                // quadratic convergence: |next step| ~ C step^2 with C estimated from the last two steps
+                float sl = fabsf(dl) * il, sv = fabsf(dv) * iv;
+                float pl = sl * sl * fminf(sl * __builtin_amdgcn_rcpf(sl_prev * sl_prev), PCS_F32_PREDICT_CMAX);
+                float pv = sv * sv * fminf(sv * __builtin_amdgcn_rcpf(sv_prev * sv_prev), PCS_F32_PREDICT_CMAX);
+                done = ((sl <= 2e-6f) && (sv <= 3e-5f)) || (it > 0 && sl < 1e-2f && sv < 1e-2f && pl <= PCS_F32_PREDICT_TOL_L && pv <= PCS_F32_PREDICT_TOL_V);
+                sl_prev = sl; sv_prev = sv;
+#else
                 done = (fabsf(dl) <= 2e-6f * rl) && (fabsf(dv) <= 3e-5f * rv);
+#endif
                 rl = rln;
                 rv = rvn;
             }
@@ -185,6 +234,7 @@ PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double&
     }
     rl_out = (double)rl;
     rv_out = (double)rv;
+    if (diag) *diag = n_liq | (n_cpl << 8) | (code << 16);  // diagnostics builds only
     return ok;  // not converged within the caps is fine: the fp64 iteration continues from here
 }
 

@@ -130,7 +130,24 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = T
     Eval l;
     bool warm = false;
 #ifdef PCS_F32_PRESOLVE
+#ifdef PCS_DIAG_ITERS
+    int diag = 0;
+    warm = vle_presolve_f32(c, rl, rv, &diag);
+#else
+#if !(defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 1)
     warm = vle_presolve_f32(c, rl, rv);  // fp32 initialiser + first iterations (pure_f32.hpp)
+#endif
+#endif
+#endif
+#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT <= 3  // timing experiments only: stop after coef (1), fp32 liquid (2), fp32 pre-solve (3)
+    {
+        double acc = rl + rv + c.m + c.mm1 + c.ceta + c.kd1 + c.kd2 + c.da + c.na + c.nb + c.qm;
+        for (int i = 0; i < 7; i++) acc += c.ai[i] + c.bi[i];
+        for (int i = 0; i < 5; i++) acc += c.j1[i];
+        for (int i = 0; i < 4; i++) acc += c.j2[i];
+        out.p_star = acc; out.rho_l = rl; out.rho_v = rv; out.iters = 0;
+        return ST_OK;
+    }
 #endif
     bool active = warm;
     if (__ballot(!warm) != 0ull) {
@@ -151,6 +168,10 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = T
         // (a warm lane carries a converged fp32 vapour density instead: only sanity-checked)
         if (!is_finite_bits(rv) || !(rv < (warm ? 0.7 : 0.05) * rl)) active = false;
     }
+#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 4  // timing experiments only: stop after the first fp64 liquid evaluation
+    out.p_star = l.p + l.dp + l.a + rv; out.rho_l = rl; out.rho_v = rv; out.iters = 0;
+    return active ? ST_OK : ST_RETRY;
+#endif
     bool done = false;
     out.iters = 0;
     for (int it = 0; it < VLE_MAX_IT; it++) {
@@ -175,6 +196,9 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = T
         if (__ballot(active && !done) == 0ull) break;
         if (active && !done) l = pure_eval(c, rl);
     }
+#if defined(PCS_DIAG_ITERS) && defined(PCS_F32_PRESOLVE)
+    out.iters |= diag << 8;
+#endif
     if (done && out.rho_v < 0.7 * out.rho_l) return ST_OK;
     return ST_RETRY;  // includes cap hit and near-critical states: let the robust path decide
 }
