@@ -148,45 +148,56 @@ PCS_DEV EvalF pure_eval_f32(const PureCoefF& c, float rho) {
 
 PCS_DEV bool finitef(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
 
+// fp32 liquid root of p(rho) = p_spec from eta = 0.5.  Newton on (p - p_spec)(1-eta)^4 = 0 (same root):
+// the hard-sphere pole makes p(rho) very steep on the dense side, the scaled function is close to
+// linear -> 2-3 evaluations instead of 4-6 to a 10 % step.  Strongly attractive rows (large dipole /
+// association at low T) have their liquid above eta = 0.5: they restart at eta = 0.58 on its dense side
+// with plain Newton (monotone from there) and the tighter `tol_dense`.
+// Wave-uniform loop; returns false when the lane must use the fp64 initialiser.
+PCS_DEV bool liquid_root_f32(const PureCoefF& f, float p_spec, float tol, float tol_dense, int cap, float& rl,
+                             int& n_eval) {
+    bool ok = finitef(f.da) && finitef(f.kd2) && finitef(f.ceta) && f.ceta > 0.0f && finitef(p_spec);
+    rl = 0.5f / f.ceta;
+    bool done = !ok, dense = false;
+    for (int it = 0; it < cap; it++) {
+        if (!done) {
+            EvalF e = pure_eval_f32(f, rl);
+            n_eval++;
+            float res = e.p - p_spec;
+            if (PCS_F32_DENSE_RESTART && it == 0 && finitef(e.p) && !(res > 0.0f)) {
+                dense = true;
+                rl = 0.58f / f.ceta;
+            } else if (!finitef(e.p) || !(e.dp > 0.0f) || (it == (dense ? 1 : 0) && !(res > 0.0f))) {
+                ok = false;
+                done = true;
+            } else {
+#ifdef PCS_LIQ_PLAIN_NEWTON
+                float step = res / e.dp;
+#else
+                float den = dense ? e.dp : e.dp - 4.0f * res * f.ceta * __builtin_amdgcn_rcpf(1.0f - rl * f.ceta);
+                float step = res * __builtin_amdgcn_rcpf(den);
+                if (!(den > 0.0f)) step = 2.0f * rl;  // -> rn < 0 -> this lane takes the fp64 initialiser
+#endif
+                float rn = rl - step;
+                if (!(rn > 0.0f)) { ok = false; done = true; }
+                else { done = fabsf(step) <= (dense ? tol_dense : tol) * rl; rl = rn; }
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+    }
+    return ok && done;
+}
+
 // fp32 pass.  Returns true with (rl, rv) close to the solution (typically 1e-6 relative) when
 // every step of the pass behaved; false = this lane must use the fp64 initialiser.
 PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double& rv_out, int* diag = nullptr) {
     int n_liq = 0, n_cpl = 0, code = 0;
     PureCoefF f;
     to_f32(c, f);
-    bool ok = finitef(f.da) && finitef(f.kd2) && finitef(f.ceta) && f.ceta > 0.0f;
-    // zero-pressure liquid, Newton from eta = 0.5 (monotone from the dense side)
-    float rl = 0.5f / f.ceta;
-    bool done = !ok, dense = false;
-    for (int it = 0; it < 12; it++) {
-        if (!done) {
-            EvalF e = pure_eval_f32(f, rl);
-            n_liq++;
-            if (PCS_F32_DENSE_RESTART && it == 0 && finitef(e.p) && !(e.p > 0.0f)) {
-                // strongly attractive row (large dipole / association at low T): the zero-pressure liquid lies
-                // above eta = 0.5; restart on its dense side (plain Newton is monotone from there)
-                dense = true;
-                rl = 0.58f / f.ceta;
-            } else if (!finitef(e.p) || !(e.dp > 0.0f) || (it == (dense ? 1 : 0) && !(e.p > 0.0f))) {
-                ok = false;
-                done = true;
-            } else {
-#ifdef PCS_LIQ_PLAIN_NEWTON
-                float step = e.p / e.dp;
-#else
-                // Newton on p (1-eta)^4 = 0 (same root): the hard-sphere pole makes p(rho) very steep on the
-                // dense side, the scaled function is close to linear -> 2-3 evaluations instead of 4-6
-                float den = dense ? e.dp : e.dp - 4.0f * e.p * f.ceta * __builtin_amdgcn_rcpf(1.0f - rl * f.ceta);
-                float step = e.p * __builtin_amdgcn_rcpf(den);
-                if (!(den > 0.0f)) step = 2.0f * rl;  // -> rn < 0 -> this lane takes the fp64 initialiser
-#endif
-                float rn = rl - step;
-                if (!(rn > 0.0f)) { ok = false; done = true; }
-                else { done = fabsf(step) <= (dense ? 1e-2f : PCS_F32_LIQ_TOL) * rl; rl = rn; }
-            }
-        }
-        if (__ballot(!done) == 0ull) break;
-    }
+    // zero-pressure liquid, handed over to the coupled iteration at a loose step
+    float rl;
+    bool ok = liquid_root_f32(f, 0.0f, PCS_F32_LIQ_TOL, 1e-2f, 12, rl, n_liq);
+    bool done = ok;
 #if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 2  // timing experiments only
     rl_out = (double)rl; rv_out = ok ? 1.0 : 2.0; return ok;
 #endif

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k_pure_liquid_density(const double* __r
     pure_coef<double>(c, par, T, false);
     double rho;
     Eval last;
-    int st = liquid_newton(c, p_red, TOL_STEP, rho, last);
+    int st = liquid_density_solve(c, p_red, TOL_STEP, rho, last);
     if (!live) return;
     // `rho` already carries the final Newton update rho - (p - p_spec)/dp (pcsaft_pure.py:198) taken
     // at a point whose relative step was <= TOL_STEP, i.e. it is converged to ~1e-11; it is both

@@ -60,13 +60,15 @@ constexpr double TOL_L_P = 1e-5, TOL_V_P = 1e-4;
 // no root at this pressure (iterate crossed the spinodal), or when the cap is hit.
 // `tol` is loose (1e-6) when used as an initialiser.
 // `skip` lanes idle through the (wave-uniform) loop and return ST_OK untouched.
-PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, double& rho, Eval& last, bool skip = false) {
-    rho = ETA_START / c.ceta;
+// `warm` lanes start from `rho` as passed in (fp32 pre-solve) instead of eta = 0.5.
+PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, double& rho, Eval& last, bool skip = false,
+                          bool warm = false) {
+    if (!warm) rho = ETA_START / c.ceta;
     bool done = skip, fail = false;
     for (int it = 0; it < LIQ_MAX_IT; it++) {
         if (!done && !fail) {
             Eval e = pure_eval(c, rho);
-            if (it == 0 && !(e.p > p_spec)) {
+            if (it == 0 && !warm && !(e.p > p_spec)) {
                 // very cold / very dense state: start further right (still eta < 0.74)
                 rho = 0.62 / c.ceta;
                 e = pure_eval(c, rho);
@@ -88,6 +90,41 @@ PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, 
         if (__ballot(!done && !fail) == 0ull) break;
     }
     return (done && !fail) ? ST_OK : ST_FAILED;
+}
+
+#ifndef PCS_K2_F32_TOL
+#define PCS_K2_F32_TOL 1e-4f
+#endif
+// Liquid density at (T, p): fp32 root (pure_f32.hpp) to its noise floor, then the fp64 Newton of
+// pcsaft_pure.py:196-199 from there (typically one evaluation).  Lanes whose fp32 pass misbehaves
+// start from eta = 0.5 in fp64.
+PCS_DEV int liquid_density_solve(const PureCoef<double>& c, double p_spec, double tol, double& rho, Eval& last) {
+    bool warm = false;
+#ifdef PCS_F32_PRESOLVE
+    {
+        PureCoefF f;
+        to_f32(c, f);
+        float rl;
+        int n_eval = 0;
+        warm = liquid_root_f32(f, (float)p_spec, PCS_K2_F32_TOL, PCS_K2_F32_TOL, 12, rl, n_eval);
+        rho = (double)rl;
+    }
+#endif
+    int st = liquid_newton(c, p_spec, tol, rho, last, false, warm);
+#ifdef PCS_F32_PRESOLVE
+    if (__ballot(warm && st != ST_OK) != 0ull) {
+        // the fp32 root was not on the liquid branch after all: redo those lanes from the dense side
+        double rho2;
+        Eval last2;
+        int st2 = liquid_newton(c, p_spec, tol, rho2, last2, !(warm && st != ST_OK), false);
+        if (warm && st != ST_OK) {
+            st = st2;
+            rho = rho2;
+            last = last2;
+        }
+    }
+#endif
+    return st;
 }
 
 struct VleResult {
