@@ -63,87 +63,38 @@ __device__ __forceinline__ void stage_params(const double* __restrict__ params, 
 #ifndef K1_WAVES
 #define K1_WAVES 2
 #endif
-#ifndef K1_TILES
-#define K1_TILES 4  // 256-row tiles per workgroup: the bucketing domain is K1_TILES * 256 rows
-#endif
-#ifndef K1_TAU_BINS
-#define K1_TAU_BINS 4
-#endif
-constexpr int K1_ROWS = K1_TILES * BLOCK;
-constexpr int K1_BINS = 4 * K1_TAU_BINS;
+constexpr int K1_BINS = 4;
 
 // Bucket key of a staged row: model class (which branches of the Helmholtz energy the row needs) in
-// Gray order none, polar, polar+assoc, assoc -- neighbouring buckets share a branch -- and a coarse
-// reduced temperature T / (1.28 eps m^0.45) (fit of the critical temperature of non-polar PC-SAFT
-// chains), which predicts the Newton iteration count.  Lanes of one wave then run the same branches
-// for about the same number of iterations.
+// Gray order none, polar, polar+assoc, assoc -- neighbouring buckets share a branch.  Lanes of one
+// wave then mostly run the same branches.  (A second key, a coarse reduced temperature as predictor of
+// the iteration count, measured 0.5-1.5 % slower on a 256-row domain: not used.)
 __device__ __forceinline__ int k1_bucket(const double* row) {
     const bool polar = row[3] != 0.0;
     const bool assoc = (row[4] != 0.0) && (row[6] != 0.0 || row[7] != 0.0);
-    const int cls = polar ? (assoc ? 2 : 1) : (assoc ? 3 : 0);
-    if (K1_TAU_BINS == 1) return cls;
-    const float m = (float)row[0], eps = (float)row[2], T = (float)row[8];
-    const float tau = T * __builtin_amdgcn_rcpf(1.28f * eps * __expf(0.45f * __logf(m)));
-    int tb = (int)((tau - 0.5f) * (2.5f * K1_TAU_BINS));  // K1_TAU_BINS buckets over [0.5, 0.9]
-    tb = tb < 0 ? 0 : (tb > K1_TAU_BINS - 1 ? K1_TAU_BINS - 1 : tb);
-    return cls * K1_TAU_BINS + tb;
+    return polar ? (assoc ? 2 : 1) : (assoc ? 3 : 0);
 }
 
-// One row per lane: coefficients, fast VLE solve, stores.  Kept out of line when the workgroup loops
-// over several tiles: inlined into the loop, LLVM hoists ~100 VGPRs of loop-invariant fp64 constants
-// out of it and spills.
-#if K1_TILES > 1
-__device__ __attribute__((noinline))
-#else
-__device__ __forceinline__
-#endif
-void k1_solve_row(const double* row, int64_t i, int64_t n, double* __restrict__ p_sat, double* __restrict__ rho_eq,
-                  double* __restrict__ rho_vl, uint8_t* __restrict__ status, int32_t* __restrict__ iters,
-                  int32_t* __restrict__ retry) {
-    double par[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) par[q] = row[q];
-    const double T = row[8];
-
-    PureCoef<double> c;
-    pure_coef<double>(c, par, T, false);
-    VleResult res;
-    int st = rho_eq ? vle_fast(c, res, 1e-8, TOL_STEP) : vle_fast(c, res);  // wave-uniform
-
-    if (i < n) {
-        if (st == ST_OK) {
-            if (p_sat) p_sat[i] = res.p_star * T * P_UNIT;
-            if (rho_eq) rho_eq[i] = res.rho_l * (1.0 / RHO_UNIT);
-            if (rho_vl) {
-                rho_vl[2 * i] = res.rho_v;
-                rho_vl[2 * i + 1] = res.rho_l;
-            }
-            if (iters) iters[i] = res.iters;
-            status[i] = 0;
-        } else {
-            status[i] = 1;  // provisional; the robust pass overwrites it
-            int slot = atomicAdd(&retry[0], 1);
-            retry[1 + slot] = (int32_t)i;  // n < 2^31 checked on the host
-        }
-    }
-}
-
+// The 256 staged rows of the workgroup are bucketed (LDS counting sort; the order inside a bucket is
+// irrelevant) and lane t solves the row at sorted position t.  A larger bucketing domain (4 tiles per
+// workgroup) measured only 2-3 % faster and costs either LDS occupancy or a non-inlined call per
+// tile whose callee-saved registers go through scratch (3.8 GB of HBM writes per 1e7 rows): not used.
 __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __restrict__ params,
                                                     const double* __restrict__ temp, int64_t n,
                                                     double* __restrict__ p_sat, double* __restrict__ rho_eq,
                                                     double* __restrict__ rho_vl, uint8_t* __restrict__ status,
                                                     int32_t* __restrict__ iters, int32_t* __restrict__ retry) {
-    __shared__ double lds[K1_ROWS * ROW_PAD];  // 8 parameters + T per row
-    __shared__ uint16_t perm[K1_ROWS];
+    __shared__ double lds[BLOCK * ROW_PAD];  // 8 parameters + T per row
+    __shared__ int perm[BLOCK];
     __shared__ int bins[K1_BINS];
     const int t = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * K1_ROWS;
-    // cooperative, coalesced staging of K1_ROWS rows (rows past n clamp to row n-1; never stored)
+    const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
+    // cooperative, coalesced staging (rows past n clamp to row n-1; never stored)
     {
         const double2* src = reinterpret_cast<const double2*>(params);
         const int64_t last2 = n * 4 - 1;
 #pragma unroll
-        for (int k = 0; k < 4 * K1_TILES; k++) {
+        for (int k = 0; k < 4; k++) {
             int idx2 = t + k * BLOCK;
             int64_t g = row0 * 4 + idx2;
             if (g > last2) g = last2 - 3 + (idx2 & 3);
@@ -152,25 +103,17 @@ __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __re
             lds[r * ROW_PAD + 2 * c2] = v.x;
             lds[r * ROW_PAD + 2 * c2 + 1] = v.y;
         }
-#pragma unroll
-        for (int k = 0; k < K1_TILES; k++) {
-            int r = t + k * BLOCK;
-            int64_t g = row0 + r;
-            lds[r * ROW_PAD + 8] = temp[g < n ? g : n - 1];
-        }
+        const int64_t g = row0 + t;
+        lds[t * ROW_PAD + 8] = temp[g < n ? g : n - 1];
         if (t < K1_BINS) bins[t] = 0;
     }
     __syncthreads();
-    // counting sort of the staged rows by bucket (LDS atomics; the order inside a bucket is irrelevant)
-    int key[K1_TILES];
-#pragma unroll
-    for (int k = 0; k < K1_TILES; k++) {
-        key[k] = k1_bucket(&lds[(t + k * BLOCK) * ROW_PAD]);
-        atomicAdd(&bins[key[k]], 1);
-    }
+    const int key = k1_bucket(&lds[t * ROW_PAD]);
+    atomicAdd(&bins[key], 1);
     __syncthreads();
     if (t == 0) {
         int acc = 0;
+#pragma unroll
         for (int b = 0; b < K1_BINS; b++) {
             int c = bins[b];
             bins[b] = acc;
@@ -178,14 +121,36 @@ __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __re
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K1_TILES; k++) perm[atomicAdd(&bins[key[k]], 1)] = (uint16_t)(t + k * BLOCK);
+    perm[atomicAdd(&bins[key], 1)] = t;
     __syncthreads();
 
-#pragma unroll 1
-    for (int k = 0; k < K1_TILES; k++) {  // no barrier below: the waves run through their tiles independently
-        const int r = perm[k * BLOCK + t];
-        k1_solve_row(&lds[r * ROW_PAD], row0 + r, n, p_sat, rho_eq, rho_vl, status, iters, retry);
+    const int r = perm[t];
+    const int64_t i = row0 + r;
+    const bool live = i < n;
+    double par[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) par[q] = lds[r * ROW_PAD + q];
+    const double T = lds[r * ROW_PAD + 8];
+
+    PureCoef<double> c;
+    pure_coef<double>(c, par, T, false);
+    VleResult res;
+    int st = rho_eq ? vle_fast(c, res, 1e-8, TOL_STEP) : vle_fast(c, res);  // wave-uniform
+
+    if (!live) return;
+    if (st == ST_OK) {
+        if (p_sat) p_sat[i] = res.p_star * T * P_UNIT;
+        if (rho_eq) rho_eq[i] = res.rho_l * (1.0 / RHO_UNIT);
+        if (rho_vl) {
+            rho_vl[2 * i] = res.rho_v;
+            rho_vl[2 * i + 1] = res.rho_l;
+        }
+        if (iters) iters[i] = res.iters;
+        status[i] = 0;
+    } else {
+        status[i] = 1;  // provisional; the robust pass overwrites it
+        int slot = atomicAdd(&retry[0], 1);
+        retry[1 + slot] = (int32_t)i;  // n < 2^31 checked on the host
     }
 }
 
@@ -289,7 +254,7 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
                            double* rho_vl, uint8_t* status, int32_t* iters, int32_t* retry, hipStream_t s) {
     hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return fail("hipMemsetAsync", e);
-    const unsigned grid = (unsigned)((n + K1_ROWS - 1) / K1_ROWS);
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(k_pure_vle, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                        iters, retry);
     e = hipGetLastError();

@@ -7,6 +7,7 @@ set -e
 TAG=${1:-r01}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
