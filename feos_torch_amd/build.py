@@ -51,5 +51,23 @@ def build(force=False, verbose=False):
     return OUT
 
 
+HOST_SRC = os.path.join(HERE, "csrc_host", "gc_encode.cpp")
+HOST_OUT = os.path.join(HERE, "_gc_encode.so")
+
+
+def build_host(force=False, verbose=False):
+    """CPython extension with the native gc row encoder (host code, g++)."""
+    if not force and os.path.exists(HOST_OUT) and os.path.getmtime(HOST_OUT) >= os.path.getmtime(HOST_SRC):
+        return HOST_OUT
+    import sysconfig
+
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", sysconfig.get_paths()["include"], "-o", HOST_OUT, HOST_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_OUT
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_host(force=True, verbose=True)

@@ -48,7 +48,19 @@ def _encode_molecule(segs, bonds, idx):
 
 
 def encode_rows(segment_identifier, segment_lists, bond_lists):
-    """[N, 80] uint8 row encoding (layout of include/pcsaft_hip.h)."""
+    """[N, 80] uint8 row encoding (layout of include/pcsaft_hip.h), by the native encoder
+    (csrc_host/gc_encode.cpp, built by feos_torch_amd.build.build_host / __graft_entry__.build)."""
+    try:
+        from . import _gc_encode
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("feos_torch_amd._gc_encode is not built: run `python -m feos_torch_amd.build`") from e
+    rows = np.zeros((len(segment_lists), 80), dtype=np.uint8)
+    _gc_encode.encode_rows(list(segment_identifier), segment_lists, bond_lists, rows)
+    return rows
+
+
+def encode_rows_py(segment_identifier, segment_lists, bond_lists):
+    """Pure-Python specification of encode_rows (tests compare the native encoder against it)."""
     idx = {s: i for i, s in enumerate(segment_identifier)}
     cache, id_cache = {}, {}
     n = len(segment_lists)
