@@ -39,7 +39,7 @@ __device__ __forceinline__ GcTable stage_table(const double* __restrict__ table,
     return tb;
 }
 
-constexpr int GC_FAST_SS = 12, GC_FAST_NEWTON = 10;  // fast-pass caps (mix_solver.hpp)
+constexpr int GC_FAST_SS = 12, GC_FAST_NEWTON = 12;  // fast-pass caps (mix_solver.hpp)
 constexpr int GC_RETRY_BLOCKS = 1024;
 
 template <bool DEW>

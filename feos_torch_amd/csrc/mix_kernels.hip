@@ -40,7 +40,7 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
     k1 = kk.y;
 }
 
-constexpr int FAST_SS = 12, FAST_NEWTON = 10;  // iteration caps of the fast pass (see mix_solver.hpp)
+constexpr int FAST_SS = 12, FAST_NEWTON = 12;  // iteration caps of the fast pass (see mix_solver.hpp)
 constexpr int MIX_RETRY_GRID = 2048;             // 64-thread workgroups of the robust pass
 
 template <bool DEW>
@@ -55,7 +55,11 @@ __device__ __forceinline__ void mix_store(int64_t i, int rc, const MixResult& r,
         double l0 = DEW ? r.inc0 : r.spec0, l1 = DEW ? r.inc1 : r.spec1;
         reinterpret_cast<double4*>(rho4)[i] = ok ? make_double4(v0, v1, l0, l1) : make_double4(0.0, 0.0, 0.0, 0.0);
     }
+#ifdef PCS_MIX_DIAG
+    if (iters) iters[i] = r.iters;
+#else
     if (iters) iters[i] = ok ? r.iters : -1;
+#endif
     status[i] = ok ? 0 : 1;
 }
 
@@ -82,7 +86,14 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
     mix_coef<double>(m.c, par, k0, k1, T);
     MixResult r;
     const double p_red = p_init[i] / (T * P_UNIT);
+#ifdef PCS_MIX_DIAG
+    long long t0 = clock64();
+#endif
     int rc = retry ? bubble_dew_solve<DEW>(m, z[i], p_red, r, FAST_SS, FAST_NEWTON) : bubble_dew_solve<DEW>(m, z[i], p_red, r);
+#ifdef PCS_MIX_DIAG
+    r.iters = (int)((clock64() - t0) >> 10);  // diagnostics builds: per-row solve time in 1024-cycle units
+    if (rc == BD_CAP && iters) iters[i] = r.iters;
+#endif
     if (rc == BD_CAP) {
         status[i] = 1;  // provisional
         retry[1 + atomicAdd(&retry[0], 1)] = (int32_t)i;
@@ -110,7 +121,13 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
         MixModel m;
         mix_coef<double>(m.c, par, k0, k1, T);
         MixResult r;
+#ifdef PCS_MIX_DIAG
+        long long t0 = clock64();
+#endif
         int rc = bubble_dew_solve<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
+#ifdef PCS_MIX_DIAG
+        r.iters = (int)((clock64() - t0) >> 10) | (1 << 30);
+#endif
         mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
     }
 }

@@ -50,6 +50,7 @@ PCS_DEV void line_eval(const Model& m, double x0, double x1, double rho, double&
     dp = 1.0 + rho * r.d2;
 }
 
+constexpr double LIQ_ROOT_TOL = 1e-6;  // relative step; the roots only initialise the phase-equilibrium Newton
 constexpr int LIQ_ROOT_MAX_IT = 30;  // Newton from the dense side needs ~5-10; a row that needs more fails
 
 // liquid-like root of p(rho) = p_spec at composition x.  Cold start: Newton from the dense side
@@ -58,7 +59,7 @@ constexpr int LIQ_ROOT_MAX_IT = 30;  // Newton from the dense side needs ~5-10; 
 template <class Model>
 PCS_DEV bool liquid_root(const Model& m, double x0, double x1, double p_spec, double& rho_out, double rho_start = 0.0) {
     double pk = m.packing(x0, x1);
-    bool warm = rho_start > 0.0;
+    bool warm = rho_start > 0.0, dense = false;
     double rho = warm ? rho_start : 0.5 / pk;
     double err_prev = 1.0;
     for (int it = 0; it < LIQ_ROOT_MAX_IT; it++) {
@@ -66,10 +67,14 @@ PCS_DEV bool liquid_root(const Model& m, double x0, double x1, double p_spec, do
         line_eval(m, x0, x1, rho, p, dp, a);
         if (!warm && it == 0 && !(p > p_spec)) {
             rho = 0.62 / pk;
+            dense = true;
             line_eval(m, x0, x1, rho, p, dp, a);
         }
-        bool bad = !(dp > 0.0) || !is_finite_bits(p);
-        double step = (p - p_spec) / dp;
+        // Newton on (p - p_spec)(1 - eta)^4 = 0 (same root, nearly linear: the hard-sphere pole is scaled out);
+        // plain Newton for the dense restart, which is monotone from above
+        double den = dense ? dp : dp - 4.0 * (p - p_spec) * pk / (1.0 - rho * pk);
+        bool bad = !(dp > 0.0) || !(den > 0.0) || !is_finite_bits(p);
+        double step = (p - p_spec) / den;
         double rho_new = rho - step;
         bad = bad || !(rho_new > 0.0) || !is_finite_bits(rho_new) || (warm && !(rho_new * pk < 0.7));
         if (bad) {
@@ -81,7 +86,7 @@ PCS_DEV bool liquid_root(const Model& m, double x0, double x1, double p_spec, do
             continue;
         }
         double err = fabs(step) / rho;
-        bool done = err <= 1e-10 || (it >= 3 && err < 1e-7 && err >= 0.25 * err_prev);
+        bool done = err <= LIQ_ROOT_TOL || (it >= 3 && err < 1e-7 && err >= 0.25 * err_prev);
         err_prev = err;
         rho = rho_new;
         if (done) {
@@ -123,6 +128,8 @@ PCS_DEV bool solve3(double A[3][4], double* x) {
 // workload; rows that need more are reported as failed (status 1), as are successive-substitution
 // runs that have not settled after SS_MAX_IT sweeps.  The CPU oracle uses the same caps.
 constexpr int SS_MAX_IT = 40;
+constexpr double SS_TOL = 1e-5;        // composition change at which the dew-point successive substitution hands over to Newton
+constexpr int NEWTON_NO_PROGRESS = 30; // Newton iterations without a new smallest step before the row is given up
 constexpr int NEWTON_MAX_IT = 60;
 
 struct MixResult {
@@ -181,7 +188,7 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
             x0 = z0;
             x1 = z1;
         }
-        double rl = 0.0;
+        double rl = 0.0, xi_prev = 0.0, res_prev = 0.0;
         bool settled = false;
         for (int ss = 0; ss < ss_max; ss++) {
             if (!liquid_root(m, x0, x1, 0.0, rl, rl) && !liquid_root(m, x0, x1, p0, rl)) return BD_FAILED;
@@ -190,13 +197,34 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
             double sum = w0 + w1;
             double n0 = w0 / sum, n1 = w1 / sum;
             double dx = fabs(n0 - x0);
-            n0 = fmin(fmax(n0, 0.2 * x0), 5.0 * x0);
-            n1 = fmin(fmax(n1, 0.2 * x1), 5.0 * x1);
-            double s2 = n0 + n1;
-            x0 = n0 / s2;
-            x1 = n1 / s2;
+            // The sweep is a scalar fixed-point map xi -> G(xi) in xi = ln(x_1/x_2); its plain iteration converges
+            // linearly (slowly for strongly non-ideal liquids), so from the second sweep on the secant step on
+            // r(xi) = G(xi) - xi is taken when it is well defined (r decreasing, step at most ln 5).
+            double xi = log(x0 / x1);
+            double res = log(n0 / n1) - xi;
+            bool secant = false;
+            if (ss > 0 && xi != xi_prev) {
+                double slope = (res - res_prev) / (xi - xi_prev);
+                if (slope < -0.05) {
+                    double dxi = fmin(fmax(-res / slope, -1.6), 1.6);
+                    double e = exp(xi + dxi);
+                    x0 = e / (1.0 + e);
+                    x1 = 1.0 / (1.0 + e);
+                    secant = true;
+                }
+            }
+            xi_prev = xi;
+            res_prev = res;
+            if (!secant) {
+                // damp when a component would change by more than a factor 5 in one sweep
+                n0 = fmin(fmax(n0, 0.2 * x0), 5.0 * x0);
+                n1 = fmin(fmax(n1, 0.2 * x1), 5.0 * x1);
+                double s2 = n0 + n1;
+                x0 = n0 / s2;
+                x1 = n1 / s2;
+            }
             p0 = 1.0 / sum;
-            if (dx < 1e-7) { settled = true; break; }
+            if (dx < SS_TOL) { settled = true; break; }
         }
         if (!settled && ss_max < SS_MAX_IT) return BD_CAP;
         if (!liquid_root(m, x0, x1, p0, rl) && !liquid_root(m, x0, x1, 0.0, rl)) return BD_FAILED;
@@ -204,7 +232,8 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
         ri1 = x1 * rl;
         rs = p0;
     }
-    double err_prev = 1.0;
+    double err_prev = 1.0, err_best = 1e300;
+    int it_best = 0;
     for (int it = 0; it < newton_max; it++) {
         PhaseEval s = phase_eval(m, z0 * rs, z1 * rs);
         PhaseEval n = phase_eval(m, ri0, ri1);
@@ -226,6 +255,10 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
         if (!solve3(A, du)) return BD_FAILED;
         double mx = fmax(fabs(du[0]), fmax(fabs(du[1]), fabs(du[2])));
         if (!is_finite_bits(mx)) return BD_FAILED;
+        // no new smallest Newton step for NEWTON_NO_PROGRESS iterations: the iteration cycles / wanders (no phase
+        // equilibrium at this state, or the EOS is ill-behaved there) -> fail now, not at the cap
+        if (mx < err_best) { err_best = mx; it_best = it; }
+        else if (it - it_best >= NEWTON_NO_PROGRESS) return BD_FAILED;
         double scale = mx > 1.0 ? 1.0 / mx : 1.0;  // at most a factor e per iteration
         rs *= exp(scale * du[0]);
         ri0 *= exp(scale * du[1]);

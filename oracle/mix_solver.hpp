@@ -19,6 +19,8 @@
 // (reduced residual Helmholtz energy density) and  F packing(F T, const F* x)  =
 // zeta3 / rho_total at composition x.  Used for PcSaftMix and GcPcSaftMix.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include "dual.hpp"
 
 namespace oracle {
@@ -60,22 +62,35 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
     return e;
 }
 
-// dense-side Newton for p(rho_total) = p_spec at fixed composition x (liquid-like root)
+// dense-side Newton for p(rho_total) = p_spec at fixed composition x (liquid-like root).
+// The iteration runs on (p - p_spec)(1 - eta)^4 = 0 (same root; the hard-sphere pole makes p steep,
+// the scaled function is nearly linear).  Only used to initialise the phase-equilibrium Newton, so
+// a relative step of LIQ_ROOT_TOL suffices.  Same logic and caps as csrc/mix_solver.hpp.
+constexpr double LIQ_ROOT_TOL = 1e-6;
+constexpr int NEWTON_NO_PROGRESS = 30;
+constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point successive substitution hands over to Newton
 template <class F, class Model>
 bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out) {
-    F rho = F(0.5) / model.packing(T, x);
+    static const bool plain = getenv("ORC_LIQ_PLAIN") != nullptr;
+    static const double tol = getenv("ORC_LIQ_TOL") ? atof(getenv("ORC_LIQ_TOL")) : LIQ_ROOT_TOL;
+    F pk = model.packing(T, x);
+    F rho = F(0.5) / pk;
     F err_prev = F(1);
+    bool dense = false;
     for (int it = 0; it < 30; it++) {  // same cap as the kernels
         F r[2] = {x[0] * rho, x[1] * rho};
         PhaseEval<F> e = eval_phase<F>(model, T, r);
         F p = e.p(), dp = x[0] * e.dp(0) + x[1] * e.dp(1);
-        if (it == 0 && !(p > p_spec)) { rho = F(0.62) / model.packing(T, x); continue; }
+        if (it == 0 && !(p > p_spec)) { rho = F(0.62) / pk; dense = true; continue; }
+        if (getenv("ORC_TRACE_LIQ")) fprintf(stderr, "  liq it %d eta %.5f p %.4e dp %.4e p_spec %.3e\n", it, (double)(rho * pk), (double)p, (double)dp, (double)p_spec);
         if (!(dp > 0) || !(p == p)) return false;
-        F step = (p - p_spec) / dp;
+        F den = (dense || plain) ? dp : dp - F(4) * (p - p_spec) * pk / (F(1) - rho * pk);
+        if (!(den > 0)) return false;
+        F step = (p - p_spec) / den;
         F rho_new = rho - step;
         if (!(rho_new > 0)) return false;
         F err = (step < 0 ? -step : step) / rho;
-        bool done = err <= F(1e-10) || (it >= 3 && err < F(1e-7) && err >= F(0.25) * err_prev);
+        bool done = err <= F(tol) || (it >= 3 && err < F(1e-7) && err >= F(0.25) * err_prev);
         err_prev = err;
         rho = rho_new;
         if (done) { rho_out = rho; return true; }
@@ -147,9 +162,13 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         //   x_i <- (y_i x_i / f_i) / sum_j (y_j x_j / f_j),   p = 1 / sum_j (y_j x_j / f_j)
         F rl = 0;
         bool have = false;
-        for (int ss = 0; ss < 40; ss++) {  // same caps as the kernels (csrc/mix_solver.hpp)
+        static const bool ss_secant = getenv("ORC_SS_PLAIN") == nullptr;
+        F xi_prev = 0, res_prev = 0;
+        static const int ss_cap = getenv("ORC_SS_CAP") ? atoi(getenv("ORC_SS_CAP")) : 40;
+        static const double ss_tol = getenv("ORC_SS_TOL") ? atof(getenv("ORC_SS_TOL")) : SS_TOL;
+        for (int ss = 0; ss < ss_cap; ss++) {  // same caps as the kernels (csrc/mix_solver.hpp)
             if (!liquid_root<F>(model, T, x, F(0), rl)) {
-                if (!liquid_root<F>(model, T, x, p0, rl)) return false;
+                if (!liquid_root<F>(model, T, x, p0, rl)) { if (getenv("ORC_TRACE")) fprintf(stderr, "FAIL ss-liquid-root ss %d x %.6e %.6e p0 %.6e\n", ss, (double)x[0], (double)x[1], (double)p0); return false; }
             }
             have = true;
             F r[2] = {x[0] * rl, x[1] * rl};
@@ -160,25 +179,52 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             F xn[2] = {w[0] / sum, w[1] / sum};
             F dx = xn[0] - x[0];
             if (dx < 0) dx = -dx;
-            // damp when a component would change by more than a factor 5 in one sweep
-            for (int i = 0; i < 2; i++) {
-                if (xn[i] > F(5) * x[i]) xn[i] = F(5) * x[i];
-                if (xn[i] < F(0.2) * x[i]) xn[i] = F(0.2) * x[i];
+            // The sweep is a scalar fixed-point map xi -> G(xi) in xi = ln(x_1/x_2); its plain iteration converges
+            // linearly (slowly for strongly non-ideal liquids), so from the second sweep on the secant step on
+            // r(xi) = G(xi) - xi is taken when it is well defined (r decreasing, step at most ln 5).
+            F xi = log(x[0] / x[1]);
+            F res = log(xn[0] / xn[1]) - xi;
+            bool secant = false;
+            if (ss_secant && ss > 0 && xi != xi_prev) {
+                F slope = (res - res_prev) / (xi - xi_prev);
+                if (slope < F(-0.05)) {
+                    F dxi = -res / slope;
+                    if (dxi > F(1.6)) dxi = F(1.6);
+                    if (dxi < F(-1.6)) dxi = F(-1.6);
+                    F e = exp(xi + dxi);
+                    xi_prev = xi;
+                    res_prev = res;
+                    x[0] = e / (F(1) + e);
+                    x[1] = F(1) / (F(1) + e);
+                    secant = true;
+                }
             }
-            F s2 = xn[0] + xn[1];
-            x[0] = xn[0] / s2;
-            x[1] = xn[1] / s2;
+            if (!secant) {
+                xi_prev = xi;
+                res_prev = res;
+                // damp when a component would change by more than a factor 5 in one sweep
+                for (int i = 0; i < 2; i++) {
+                    if (xn[i] > F(5) * x[i]) xn[i] = F(5) * x[i];
+                    if (xn[i] < F(0.2) * x[i]) xn[i] = F(0.2) * x[i];
+                }
+                F s2 = xn[0] + xn[1];
+                x[0] = xn[0] / s2;
+                x[1] = xn[1] / s2;
+            }
             p0 = F(1) / sum;
-            if (dx < F(1e-7)) break;
+            if (getenv("ORC_TRACE")) fprintf(stderr, "ss %d x %.6e %.6e p0 %.6e rl %.6e dx %.3e\n", ss, (double)x[0], (double)x[1], (double)p0, (double)rl, (double)dx);
+            if (dx < F(ss_tol)) break;
         }
         if (!have) return false;
-        if (!liquid_root<F>(model, T, x, p0, rl) && !liquid_root<F>(model, T, x, F(0), rl)) return false;
+        if (!liquid_root<F>(model, T, x, p0, rl) && !liquid_root<F>(model, T, x, F(0), rl)) { if (getenv("ORC_TRACE")) fprintf(stderr, "FAIL post-ss liquid root x %.6e %.6e p0 %.6e\n", (double)x[0], (double)x[1], (double)p0); return false; }
         ri[0] = x[0] * rl;
         ri[1] = x[1] * rl;
         rs = p0;  // ideal vapour
     }
     // Newton in (ln rho_spec, ln rho_inc_1, ln rho_inc_2)
-    F err_prev = F(1);
+    F err_prev = F(1), err_best = F(1e300);
+    int it_best = 0;
+    static const int no_progress = getenv("ORC_NP") ? atoi(getenv("ORC_NP")) : NEWTON_NO_PROGRESS;
     for (int it = 0; it < 60; it++) {
         F r_s[2] = {z[0] * rs, z[1] * rs};
         PhaseEval<F> s = eval_phase<F>(model, T, r_s);
@@ -198,10 +244,15 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         F mx = 0;
         for (int k = 0; k < 3; k++) { F a = du[k] < 0 ? -du[k] : du[k]; if (a > mx) mx = a; }
         if (!(mx == mx)) return false;
+        // no new smallest Newton step for NEWTON_NO_PROGRESS iterations: the iteration cycles / wanders
+        // (no phase equilibrium at this state, or the EOS is ill-behaved there) -> fail now, not at the cap
+        if (mx < err_best) { err_best = mx; it_best = it; }
+        else if (it - it_best >= no_progress) return false;
         F scale = mx > F(1) ? F(1) / mx : F(1);  // at most a factor e per iteration
         rs = rs * exp(scale * du[0]);
         ri[0] = ri[0] * exp(scale * du[1]);
         ri[1] = ri[1] * exp(scale * du[2]);
+        if (getenv("ORC_TRACE")) fprintf(stderr, "it %d mx %.3e du %.3e %.3e %.3e rs %.6e ri %.6e %.6e F %.3e %.3e %.3e\n", it, (double)mx, (double)du[0], (double)du[1], (double)du[2], (double)rs, (double)ri[0], (double)ri[1], (double)Fv[0], (double)Fv[1], (double)Fv[2]);
         info.iters = it + 1;
         bool stagnated = it >= 3 && mx < F(1e-7) && mx >= F(0.25) * err_prev;
         err_prev = mx;
