@@ -22,7 +22,15 @@ constexpr int MBLOCK = 128;
 
 struct MixModel {
     MixCoef<double> c;
+#if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2  // diagnostics builds: evaluation counters
+    mutable int n_line = 0, n_phase = 0;
+    template <class R> PCS_DEV R a(const R& r0, const R& r1) const {
+        if (sizeof(R) == sizeof(T2<double>)) n_phase++; else n_line++;
+        return mix_a<double, R>(c, r0, r1);
+    }
+#else
     template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return mix_a<double, R>(c, r0, r1); }
+#endif
     PCS_DEV double packing(double x0, double x1) const { return x0 * c.zk[3][0] + x1 * c.zk[3][1]; }
 };
 
@@ -40,7 +48,11 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
     k1 = kk.y;
 }
 
-constexpr int FAST_SS = 12, FAST_NEWTON = 12;  // iteration caps of the fast pass (see mix_solver.hpp)
+#ifndef PCS_FAST_SS
+#define PCS_FAST_SS 12
+#define PCS_FAST_NEWTON 12
+#endif
+constexpr int FAST_SS = PCS_FAST_SS, FAST_NEWTON = PCS_FAST_NEWTON;  // iteration caps of the fast pass (see mix_solver.hpp)
 constexpr int MIX_RETRY_GRID = 2048;             // 64-thread workgroups of the robust pass
 
 template <bool DEW>
@@ -91,7 +103,11 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
 #endif
     int rc = retry ? bubble_dew_solve<DEW>(m, z[i], p_red, r, FAST_SS, FAST_NEWTON) : bubble_dew_solve<DEW>(m, z[i], p_red, r);
 #ifdef PCS_MIX_DIAG
+#if PCS_MIX_DIAG == 2
+    r.iters = m.n_phase | (m.n_line << 12);
+#else
     r.iters = (int)((clock64() - t0) >> 10);  // diagnostics builds: per-row solve time in 1024-cycle units
+#endif
     if (rc == BD_CAP && iters) iters[i] = r.iters;
 #endif
     if (rc == BD_CAP) {
@@ -126,7 +142,11 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
 #endif
         int rc = bubble_dew_solve<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
 #ifdef PCS_MIX_DIAG
+#if PCS_MIX_DIAG == 2
+        r.iters = m.n_phase | (m.n_line << 12) | (1 << 30);
+#else
         r.iters = (int)((clock64() - t0) >> 10) | (1 << 30);
+#endif
 #endif
         mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
     }

@@ -163,18 +163,37 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         F rl = 0;
         bool have = false;
         static const bool ss_secant = getenv("ORC_SS_PLAIN") == nullptr;
+        static const bool ss_track = getenv("ORC_SS_NOTRACK") == nullptr;
         F xi_prev = 0, res_prev = 0;
         static const int ss_cap = getenv("ORC_SS_CAP") ? atoi(getenv("ORC_SS_CAP")) : 40;
         static const double ss_tol = getenv("ORC_SS_TOL") ? atof(getenv("ORC_SS_TOL")) : SS_TOL;
         for (int ss = 0; ss < ss_cap; ss++) {  // same caps as the kernels (csrc/mix_solver.hpp)
-            if (!liquid_root<F>(model, T, x, F(0), rl)) {
-                if (!liquid_root<F>(model, T, x, p0, rl)) { if (getenv("ORC_TRACE")) fprintf(stderr, "FAIL ss-liquid-root ss %d x %.6e %.6e p0 %.6e\n", ss, (double)x[0], (double)x[1], (double)p0); return false; }
+            // The liquid density is not re-solved in every sweep: the evaluation at (x, rl) gives p and dp/drho along x,
+            // i.e. the Newton step drho to the zero-pressure root, and the chemical potentials are carried to that
+            // root to first order with the Hessian.  A full root solve is done at the start and whenever the step is
+            // not small (composition moved a lot) or the linearisation is unusable.
+            PhaseEval<F> e;
+            F drho = F(0);
+            for (int attempt = 0; attempt < 2; attempt++) {
+                if (!have || attempt == 1) {
+                    if (!liquid_root<F>(model, T, x, F(0), rl) && !liquid_root<F>(model, T, x, p0, rl)) {
+                        if (getenv("ORC_TRACE")) fprintf(stderr, "FAIL ss-liquid-root ss %d x %.6e %.6e p0 %.6e\n", ss, (double)x[0], (double)x[1], (double)p0);
+                        return false;
+                    }
+                    have = true;
+                }
+                F r[2] = {x[0] * rl, x[1] * rl};
+                e = eval_phase<F>(model, T, r);
+                F p = e.p(), dp = x[0] * e.dp(0) + x[1] * e.dp(1);
+                drho = -p / dp;
+                F ad = drho < 0 ? -drho : drho;
+                if (ss_track && dp > 0 && p == p && ad <= F(0.05) * rl) break;
+                if (attempt == 1) { if (!(dp > 0) || !(p == p)) return false; if (!(ad <= F(0.05) * rl)) drho = F(0); }
             }
-            have = true;
-            F r[2] = {x[0] * rl, x[1] * rl};
-            PhaseEval<F> e = eval_phase<F>(model, T, r);
+            F rlc = rl + drho;
             F w[2];
-            for (int i = 0; i < 2; i++) w[i] = z[i] * x[i] / (r[i] * exp(e.g[i]));
+            for (int i = 0; i < 2; i++) w[i] = z[i] / (rlc * exp(e.g[i] + (x[0] * e.h[i][0] + x[1] * e.h[i][1]) * drho));
+            rl = rlc;
             F sum = w[0] + w[1];
             F xn[2] = {w[0] / sum, w[1] / sum};
             F dx = xn[0] - x[0];
@@ -216,7 +235,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             if (dx < F(ss_tol)) break;
         }
         if (!have) return false;
-        if (!liquid_root<F>(model, T, x, p0, rl) && !liquid_root<F>(model, T, x, F(0), rl)) { if (getenv("ORC_TRACE")) fprintf(stderr, "FAIL post-ss liquid root x %.6e %.6e p0 %.6e\n", (double)x[0], (double)x[1], (double)p0); return false; }
+        if (!ss_track && !liquid_root<F>(model, T, x, p0, rl) && !liquid_root<F>(model, T, x, F(0), rl)) return false;
         ri[0] = x[0] * rl;
         ri[1] = x[1] * rl;
         rs = p0;  // ideal vapour
