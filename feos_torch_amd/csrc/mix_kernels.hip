@@ -18,7 +18,10 @@ using namespace pcs_abi;
 
 namespace {
 
-constexpr int MBLOCK = 128;
+#ifndef PCS_MBLOCK
+#define PCS_MBLOCK 128
+#endif
+constexpr int MBLOCK = PCS_MBLOCK;
 
 struct MixModel {
     MixCoef<double> c;
@@ -55,6 +58,20 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
 constexpr int FAST_SS = PCS_FAST_SS, FAST_NEWTON = PCS_FAST_NEWTON;  // iteration caps of the fast pass (see mix_solver.hpp)
 constexpr int MIX_RETRY_GRID = 2048;             // 64-thread workgroups of the robust pass
 
+constexpr int MIX_BINS = 8;
+// association class (none, self, induced, cross: mix_model.hpp) x polarity of a parameter row [2][8]
+__device__ __forceinline__ int mix_bucket(const double* __restrict__ row) {
+    const double na0 = row[6], nb0 = row[7], na1 = row[14], nb1 = row[15];
+    const int associating = (na0 + nb0 != 0.0) + (na1 + nb1 != 0.0);
+    const int self_assoc = (na0 * nb0 != 0.0) + (na1 * nb1 != 0.0);
+    int cls = 0;
+    if (associating == 1 && self_assoc == 1) cls = 1;
+    if (associating == 2 && self_assoc == 1) cls = 2;
+    if (associating == 2 && self_assoc == 2) cls = 3;
+    const int polar = (row[3] != 0.0) || (row[11] != 0.0);
+    return 2 * cls + polar;
+}
+
 template <bool DEW>
 __device__ __forceinline__ void mix_store(int64_t i, int rc, const MixResult& r, double T, double* __restrict__ p_out,
                                           double* __restrict__ rho4, uint8_t* __restrict__ status,
@@ -89,7 +106,32 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
                                                            double* __restrict__ p_out, double* __restrict__ rho4,
                                                            uint8_t* __restrict__ status, int32_t* __restrict__ iters,
                                                            int32_t* __restrict__ retry) {
-    const int64_t i = (int64_t)blockIdx.x * MBLOCK + threadIdx.x;
+    // bucket the rows of the workgroup by association class and polarity (LDS counting sort) so the lanes of
+    // a wave mostly run the same branches of the Helmholtz energy: the cross-association site-fraction solve
+    // costs ~5x the rest of an evaluation and would otherwise be paid by every wave
+    __shared__ int perm[MBLOCK];
+    __shared__ int bins[MIX_BINS + 1];
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * MBLOCK;
+    if (t <= MIX_BINS) bins[t] = 0;
+    __syncthreads();
+    int key = MIX_BINS;  // rows past n sort last
+    if (row0 + t < n) key = mix_bucket(params + 16 * (row0 + t));
+    atomicAdd(&bins[key], 1);
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+#pragma unroll
+        for (int b = 0; b <= MIX_BINS; b++) {
+            int c = bins[b];
+            bins[b] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+    perm[atomicAdd(&bins[key], 1)] = t;
+    __syncthreads();
+    const int64_t i = row0 + perm[t];
     if (i >= n) return;
     double par[16], k0, k1;
     load_mix_row(params, kij, i, par, k0, k1);
