@@ -8,9 +8,12 @@
 One step = one pass of the hot path (pcs_pure_vle: fused Helmholtz + Newton/VLE kernel and the
 robust pass for rare rows) over one batch of `--rows` synthetic state points per GPU
 (SURVEY.md §8d distribution, seed 2026 + rank), inputs resident in HBM.  Weak scaling: every
-rank solves its own `--rows` rows; for N > 1 the (p_sat fp64, status u8) shards are re-assembled
-on every rank with an RCCL all-gather that is chunk-overlapped with the solve (the only
-exchange the path has).  Rank 0 prints ONE JSON line.
+rank solves its own `--rows` rows and keeps its results (rows are independent: the path has no
+exchange step, so there is no data-path collective; the step time is the MAX over ranks between
+two barriers).  `--gather` additionally re-assembles the (p_sat fp64, status u8) shards on every
+rank with an RCCL all-gather, chunk-overlapped with the solve, for callers that need the whole
+result everywhere (90 MB per rank and step: over xGMI that costs more than the 1.7 ms solve).
+Rank 0 prints ONE JSON line.
 
 The line also carries
   roofline      for the dominant kernel k_pure_vle: algorithmic bytes (81 B/solve) / its launch
@@ -43,7 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=10_000_000, help="state points per GPU per step")
     ap.add_argument("--chunks", type=int, default=4, help="sub-batches per step (gather/solve overlap, N>1)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the output all-gather")
+    ap.add_argument("--gather", action="store_true",
+                    help="N>1: also re-assemble (p_sat, status) on every rank with an RCCL all-gather, chunk-overlapped with the solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40_000_000, help="upper bound on the rows of the CPU baseline sample")
     return ap.parse_args()
@@ -87,7 +91,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback in the product path)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     rows = args.rows
-    nchunk = args.chunks if (world > 1 and not args.no_gather) else 1
+    nchunk = args.chunks if (world > 1 and args.gather) else 1
     assert rows % nchunk == 0
 
     # ---- inputs resident in HBM --------------------------------------------------------------
@@ -98,7 +102,7 @@ def main():
     plans = [native.PureVlePlan(crow, device) for _ in range(nchunk)]
     Pc = [Pd[k * crow:(k + 1) * crow] for k in range(nchunk)]
     Tc = [Td[k * crow:(k + 1) * crow] for k in range(nchunk)]
-    gather = world > 1 and not args.no_gather
+    gather = world > 1 and args.gather
     if gather:
         g_p = [torch.empty(world * crow, dtype=torch.float64, device=device) for _ in range(nchunk)]
         g_s = [torch.empty(world * crow, dtype=torch.uint8, device=device) for _ in range(nchunk)]
@@ -168,7 +172,7 @@ def main():
                 "workload": f"PcSaftPure.vapor_pressure batch={rows:.0e} fp64 per GPU (fused Helmholtz+Newton kernel)",
                 "rows_per_gpu": rows,
                 "global_rows": world * rows,
-                "parallelism": f"row-sharded x{world}" + (", all-gather(p_sat,status) overlapped" if gather else ""),
+                "parallelism": f"row-sharded x{world}" + (", all-gather(p_sat,status) overlapped" if gather else ", no data-path collective"),
                 "seed": 2026,
                 "failed_rows_rank0": fails,
                 "robust_pass_rows_rank0": retry_rows,
