@@ -110,6 +110,44 @@ def test_random_rows_vs_oracle(amd, oracle, table, dew):
     assert eos.rows.shape[0] == int((~nn).sum()) and eos.phi.shape[0] == int((~nn).sum())
 
 
+@pytest.mark.parametrize("dew", [False, True])
+def test_phase_equilibrium_conditions_large_batch(amd, table, dew):
+    """size-independent check at 1e6 rows (config 5): equal chemical potentials and pressures."""
+    from feos_torch_amd import native
+    from feos_torch_amd.gc_pcsaft import build_table, encode_rows
+    from feos_torch_amd.synthetic import gc_batch
+
+    n = 1_000_000
+    b = gc_batch(n, table, seed=43)
+    ident = [s for s, _ in table]
+    S = len(ident)
+    rows = torch.from_numpy(encode_rows(ident, b["segment_lists"], b["bond_lists"])).cuda()
+    seg = torch.tensor(np.stack([v for _, v in table]), dtype=f64)
+    kab = torch.zeros((S, S), dtype=f64)
+    for s1, s2, k in b["kab_list"]:
+        kab[ident.index(s1), ident.index(s2)] = k
+        kab[ident.index(s2), ident.index(s1)] = k
+    tab = build_table(seg.cuda(), kab.cuda())
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    phi, T, z = t(b["phi"]), t(b["T"]), t(b["x"])
+    r = native.gc_bubble_dew(tab, S, rows, phi, T, z, t(b["p_init"]), dew)
+    ok = ~r["status"]
+    assert ok.float().mean().item() > 0.999
+    rv, rl = r["rho4"][:, 0:2], r["rho4"][:, 2:4]
+    fill = lambda x: torch.where(ok[:, None], x, torch.full_like(x, 1e-3))
+    aV, pV, muV, _ = native.gc_derivatives(tab, S, rows, phi, T, fill(rv))
+    aL, pL, muL, _ = native.gc_derivatives(tab, S, rows, phi, T, fill(rl))
+    dmu = (torch.log(rv) + muV - torch.log(rl) - muL)[ok]
+    assert torch.max(torch.abs(dmu)).item() < 1e-6
+    assert torch.quantile(torch.abs(dmu).max(dim=1).values[:200000], 0.999).item() < 1e-10
+    p_red = (r["p"] / (T * 1.380649e-23 / 1e-30))[ok]
+    assert torch.max(torch.abs(pV[ok] / p_red - 1)).item() < 1e-6
+    assert torch.max(torch.abs(pL[ok] - p_red)).item() < 1e-9  # reduced units; the liquid pressure is stiff in the density
+    spec = rv if dew else rl
+    assert torch.max(torch.abs((spec[:, 0] / spec.sum(dim=1))[ok] - z[ok])).item() < 1e-12
+    assert torch.all(rv.sum(dim=1)[ok] < rl.sum(dim=1)[ok])
+
+
 def test_ffi_mirror_and_errors(amd, oracle, table, gg):
     g = gg["test_bubble"]
     kab = [(a, b, k) for (a, b), k in zip(g["kab_pairs"], g["kab_vals"])]
