@@ -9,6 +9,15 @@
 #include "abi_common.hpp"
 #include "gc_model.hpp"
 #include "mix_solver.hpp"
+#include "mix_solver_sm.hpp"
+#ifndef PCS_MIX_SM
+#define PCS_MIX_SM 1  // 1: state-machine form of the solver (mix_solver_sm.hpp), 0: sequential form
+#endif
+#if PCS_MIX_SM
+#define PCS_BD_SOLVE bubble_dew_solve_sm
+#else
+#define PCS_BD_SOLVE bubble_dew_solve
+#endif
 
 using namespace pcs;
 using namespace pcs_abi;
@@ -85,8 +94,8 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
         gc_coef<double>(m.c, rows + (size_t)i * GC_ROW_BYTES, tb, phi[2 * i], phi[2 * i + 1], T);
         MixResult r;
         const double p_red = p_init[i] / (T * P_UNIT);
-        int rc = (!RETRY && retry) ? bubble_dew_solve<DEW>(m, z[i], p_red, r, GC_FAST_SS, GC_FAST_NEWTON)
-                                   : bubble_dew_solve<DEW>(m, z[i], p_red, r);
+        const bool fast = !RETRY && retry;
+        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT);
         if (!RETRY && rc == BD_CAP) {
             status[i] = 1;  // provisional
             retry[1 + atomicAdd(&retry[0], 1)] = (int32_t)i;

@@ -11,6 +11,15 @@
 #include "abi_common.hpp"
 #include "mix_model.hpp"
 #include "mix_solver.hpp"
+#include "mix_solver_sm.hpp"
+#ifndef PCS_MIX_SM
+#define PCS_MIX_SM 1  // 1: state-machine form of the solver (mix_solver_sm.hpp), 0: sequential form
+#endif
+#if PCS_MIX_SM
+#define PCS_BD_SOLVE bubble_dew_solve_sm
+#else
+#define PCS_BD_SOLVE bubble_dew_solve
+#endif
 #include "mix_jacobian.hpp"
 
 using namespace pcs;
@@ -51,6 +60,12 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
     k1 = kk.y;
 }
 
+#ifndef PCS_MIX_QUEUE
+#define PCS_MIX_QUEUE 1  // 1: class-ordered work queue with persistent waves, 0: fast pass + retry pass
+#endif
+#ifndef PCS_QUEUE_WAVES_PER_SIMD
+#define PCS_QUEUE_WAVES_PER_SIMD 1
+#endif
 #ifndef PCS_FAST_SS
 #define PCS_FAST_SS 12
 #define PCS_FAST_NEWTON 12
@@ -143,9 +158,11 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
 #ifdef PCS_MIX_DIAG
     long long t0 = clock64();
 #endif
-    int rc = retry ? bubble_dew_solve<DEW>(m, z[i], p_red, r, FAST_SS, FAST_NEWTON) : bubble_dew_solve<DEW>(m, z[i], p_red, r);
+    int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, retry ? FAST_SS : SS_MAX_IT, retry ? FAST_NEWTON : NEWTON_MAX_IT);
 #ifdef PCS_MIX_DIAG
-#if PCS_MIX_DIAG == 2
+#if PCS_MIX_DIAG == 3
+    // r.iters already holds the evaluation count
+#elif PCS_MIX_DIAG == 2
     r.iters = m.n_phase | (m.n_line << 12);
 #else
     r.iters = (int)((clock64() - t0) >> 10);  // diagnostics builds: per-row solve time in 1024-cycle units
@@ -182,15 +199,128 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
 #ifdef PCS_MIX_DIAG
         long long t0 = clock64();
 #endif
-        int rc = bubble_dew_solve<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
+        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
 #ifdef PCS_MIX_DIAG
-#if PCS_MIX_DIAG == 2
+#if PCS_MIX_DIAG == 3
+        r.iters |= (1 << 30);
+#elif PCS_MIX_DIAG == 2
         r.iters = m.n_phase | (m.n_line << 12) | (1 << 30);
 #else
         r.iters = (int)((clock64() - t0) >> 10) | (1 << 30);
 #endif
 #endif
         mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5 as a work queue.  The iteration counts of the rows differ by an order of magnitude (5 ... 400
+// evaluations), so with one row per lane a wave idles most of its lanes most of the time.  Here the
+// rows are first ordered by class (device counting sort -> perm, expensive classes first so their long
+// rows overlap with the bulk), then a fixed set of resident waves works through that order: a lane that
+// finishes its row stores it and takes the next one, every pass of the wave's loop is one evaluation
+// for all its lanes.  No second pass: slow rows just keep their lane longer.
+// control block (int32, after perm[n] in the workspace): [0..8] class counts -> offsets, [16] queue head
+// ------------------------------------------------------------------------------------------
+constexpr int QCTRL_HEAD = 16, QCTRL_INTS = 64;
+constexpr int QCHUNK = 64;  // rows a wave reserves per atomic on the queue head
+
+__device__ __forceinline__ int mix_queue_bin(const double* __restrict__ row) { return MIX_BINS - 1 - mix_bucket(row); }
+
+__global__ __launch_bounds__(256) void k_mix_class_count(const double* __restrict__ params, int64_t n,
+                                                         int32_t* __restrict__ ctrl) {
+    __shared__ int cnt[MIX_BINS];
+    if (threadIdx.x < MIX_BINS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[mix_queue_bin(params + 16 * i)], 1);
+    __syncthreads();
+    if (threadIdx.x < MIX_BINS && cnt[threadIdx.x]) atomicAdd(&ctrl[threadIdx.x], cnt[threadIdx.x]);
+}
+
+__global__ void k_mix_class_scan(int32_t* __restrict__ ctrl) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < MIX_BINS; b++) {
+            int c = ctrl[b];
+            ctrl[b] = acc;
+            acc += c;
+        }
+        ctrl[QCTRL_HEAD] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mix_class_scatter(const double* __restrict__ params, int64_t n,
+                                                           int32_t* __restrict__ ctrl, int32_t* __restrict__ perm) {
+    __shared__ int cnt[MIX_BINS], base[MIX_BINS];
+    if (threadIdx.x < MIX_BINS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int bin = 0, rank = 0;
+    if (i < n) {
+        bin = mix_queue_bin(params + 16 * i);
+        rank = atomicAdd(&cnt[bin], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < MIX_BINS && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&ctrl[threadIdx.x], cnt[threadIdx.x]);
+    __syncthreads();
+    if (i < n) perm[base[bin] + rank] = (int32_t)i;
+}
+
+template <bool DEW>
+__global__ __launch_bounds__(64) void k_mix_bubble_dew_queue(const double* __restrict__ params,
+                                                             const double* __restrict__ kij,
+                                                             const double* __restrict__ temp,
+                                                             const double* __restrict__ z,
+                                                             const double* __restrict__ p_init, int64_t n,
+                                                             const int32_t* __restrict__ perm, int32_t* __restrict__ ctrl,
+                                                             double* __restrict__ p_out, double* __restrict__ rho4,
+                                                             uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
+    const int lane = threadIdx.x;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int total = (int)n;
+    int next = 0, end = 0;  // this wave's reserved slice [next, end) of the queue (wave-uniform)
+    bool drained = false;   // queue head passed n (wave-uniform)
+    BdLane<DEW> L;
+    L.idle();
+    MixModel m;
+    int64_t row = -1;
+    double T = 0.0;
+    for (;;) {
+        // hand rows to the lanes that have none
+        unsigned long long need = __ballot(L.done());
+        while (need != 0ull && !(drained && next >= end)) {
+            if (next >= end) {
+                int head = 0;
+                if (lane == 0) head = atomicAdd(&ctrl[QCTRL_HEAD], QCHUNK);
+                head = __builtin_amdgcn_readfirstlane(head);
+                next = head;
+                end = head + QCHUNK < total ? head + QCHUNK : total;
+                if (head >= total) { drained = true; next = end = 0; break; }
+            }
+            const int avail = end - next;
+            const int rank = __popcll(need & below);
+            const bool take = L.done() && ((need >> lane) & 1ull) && rank < avail;
+            if (take) {
+                row = perm[next + rank];
+                double par[16], k0, k1;
+                load_mix_row(params, kij, row, par, k0, k1);
+                T = temp[row];
+                mix_coef<double>(m.c, par, k0, k1, T);
+                L.start(m, z[row], p_init[row] / (T * P_UNIT));
+            }
+            const int wanted = __popcll(need);
+            next += wanted < avail ? wanted : avail;
+            need = __ballot(L.done());
+        }
+        if (__ballot(!L.done()) == 0ull) break;  // nothing in flight and nothing left to take
+        if (!L.done()) {
+            double e0, e1;
+            L.point(e0, e1);
+            PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
+            L.consume(m, e);
+            if (L.done()) mix_store<DEW>(row, L.rc, L.out, T, p_out, rho4, status, iters);
+        }
     }
 }
 
@@ -237,6 +367,18 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* 
     for (int k = 0; k < MIX_DIRS; k++) jac[MIX_DIRS * i + k] = g[k];
 }
 
+// resident waves of the queue kernel: one per SIMD (the evaluation needs the whole register file)
+int queue_waves() {
+    static int waves = 0;
+    if (!waves) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        waves = cus * 4 * PCS_QUEUE_WAVES_PER_SIMD;
+    }
+    return waves;
+}
+
 }  // namespace
 
 extern "C" {
@@ -250,6 +392,31 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
     if (!params || !kij || !temp || !z || !p_init || !status) return fail_msg("pcs_mix_bubble_dew: null required pointer");
     const unsigned grid = (unsigned)((n + MBLOCK - 1) / MBLOCK);
     hipStream_t s = as_stream(stream);
+#if PCS_MIX_QUEUE
+    if (workspace) {
+        // work-queue schedule: perm[n] + control block in the workspace
+        int32_t* perm = static_cast<int32_t*>(workspace);
+        int32_t* ctrl = perm + n;
+        hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int32_t) * QCTRL_INTS, s);
+        if (e != hipSuccess) return fail("hipMemsetAsync", e);
+        const unsigned g256 = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);
+        hipLaunchKernelGGL(k_mix_class_scan, dim3(1), dim3(64), 0, s, ctrl);
+        hipLaunchKernelGGL(k_mix_class_scatter, dim3(g256), dim3(256), 0, s, params, n, ctrl, perm);
+        unsigned waves = (unsigned)queue_waves();
+        const unsigned needed = (unsigned)((n + 63) / 64);
+        if (waves > needed) waves = needed;
+        if (dew)
+            hipLaunchKernelGGL(k_mix_bubble_dew_queue<true>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
+                               (const int32_t*)perm, ctrl, p_out, rho4, status, iters);
+        else
+            hipLaunchKernelGGL(k_mix_bubble_dew_queue<false>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
+                               (const int32_t*)perm, ctrl, p_out, rho4, status, iters);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail("k_mix_bubble_dew_queue launch", e);
+        return 0;
+    }
+#endif
     int32_t* retry = static_cast<int32_t*>(workspace);
     if (retry) {
         hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);

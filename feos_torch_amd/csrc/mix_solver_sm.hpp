@@ -1,0 +1,287 @@
+// bubble_dew_solve as a per-lane state machine around ONE evaluation site (device only).
+//
+// Same algorithm, constants and decisions as bubble_dew_solve() in mix_solver.hpp (which documents
+// them and which the CPU oracle restates); what changes is the control flow.  The sequential form
+// nests loops (pure-liquid roots, successive substitution with occasional root re-solves, Newton)
+// whose trip counts differ per lane, so a wave executes the union of all lanes' paths one after
+// the other.  Here every lane carries its stage in registers and each pass of the single wave-level
+// loop performs exactly one T2 evaluation for every unfinished lane, whatever stage it is in: the
+// wave's cost is the largest per-lane evaluation count, not the sum over code paths.
+//
+// Differences in arithmetic (all below the solver tolerances, parity tests unchanged):
+//  * liquid roots take p and dp/drho along the composition from the T2 evaluation
+//    (dp = x0 dp/drho_0 + x1 dp/drho_1) instead of a separate D2 line evaluation;
+//  * where the sequential form re-evaluates at a freshly converged root (pure-liquid fugacities,
+//    the bubble-point liquid, the first sweep), the last root evaluation is carried to the root to
+//    first order with the Hessian (the step is <= 1e-6 relative).
+#pragma once
+#include "mix_solver.hpp"
+
+namespace pcs {
+
+// Per-lane solver state.  start() -> { point(); e = phase_eval(...); consume(e); } until done().
+template <bool DEW>
+struct BdLane {
+    enum : int { S_ROOT, S_SS, S_NEWTON_S, S_NEWTON_N, S_FINAL_S, S_FINAL_N, S_DONE };
+    enum : int { R_PURE0, R_PURE1, R_SS, R_BUBBLE };  // who asked for the liquid root
+    int stage, rc;
+    double z0, z1, p_init;
+    int ss_max, newton_max;
+    // liquid-root sub-machine
+    int r_for, r_it;
+    bool r_dense, r_has_alt;
+    double r_x0, r_x1, r_pk, r_rho, r_pspec, r_palt, r_errprev;
+    // dew initialisation
+    double f0, x0, x1, p0, rl, xi_prev, res_prev;
+    int ss;
+    bool resolved;
+    // Newton
+    double rs, ri0, ri1, err_prev, err_best;
+    int it, it_best;
+    PhaseEval sv;
+    MixResult out;
+
+    PCS_DEV void idle() { stage = S_DONE; rc = BD_FAILED; }
+    PCS_DEV bool done() const { return stage == S_DONE; }
+
+    template <class Model>
+    PCS_DEV void start_root(const Model& m, int who, double xa, double xb, double pspec, bool has_alt, double palt) {
+        r_for = who;
+        r_x0 = xa;
+        r_x1 = xb;
+        r_pk = m.packing(xa, xb);
+        r_rho = 0.5 / r_pk;
+        r_pspec = pspec;
+        r_has_alt = has_alt;
+        r_palt = palt;
+        r_it = 0;
+        r_dense = false;
+        r_errprev = 1.0;
+        stage = S_ROOT;
+    }
+
+    template <class Model>
+    PCS_DEV void start(const Model& m, double z0_, double p_init_, int ss_max_ = SS_MAX_IT, int newton_max_ = NEWTON_MAX_IT) {
+        z0 = z0_; z1 = 1.0 - z0_; p_init = p_init_;
+        ss_max = ss_max_; newton_max = newton_max_;
+        rc = BD_FAILED;
+        f0 = 0.0; x0 = z0; x1 = z1; p0 = p_init; rl = 0.0; xi_prev = 0.0; res_prev = 0.0;
+        ss = 0;
+        resolved = false;
+        rs = 0.0; ri0 = 0.0; ri1 = 0.0; err_prev = 1.0; err_best = 1e300;
+        it = 0; it_best = 0;
+        sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
+        out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
+        out.iters = 0;
+        if (DEW) start_root(m, R_PURE0, 1.0, 0.0, 0.0, false, 0.0);
+        else start_root(m, R_BUBBLE, z0, z1, p_init, true, 0.0);
+    }
+
+    // partial densities of this lane's next evaluation
+    PCS_DEV void point(double& e0, double& e1) const {
+        if (stage == S_ROOT) { e0 = r_x0 * r_rho; e1 = r_x1 * r_rho; }
+        else if (stage == S_SS) { e0 = x0 * rl; e1 = x1 * rl; }
+        else if (stage == S_NEWTON_S || stage == S_FINAL_S) { e0 = z0 * rs; e1 = z1 * rs; }
+        else { e0 = ri0; e1 = ri1; }
+    }
+
+    template <class Model>
+    PCS_DEV void consume(const Model& m, const PhaseEval& e) {
+#define PCS_SM_START_ROOT(who, xa, xb, pspec, has_alt, palt) start_root(m, who, xa, xb, pspec, has_alt, palt)
+        if (stage == S_ROOT) {
+            double p = e.p(), dp = r_x0 * e.dp0() + r_x1 * e.dp1();
+            if (r_it == 0 && !r_dense && !(p > r_pspec)) {
+                r_rho = 0.62 / r_pk;  // very cold / dense: restart on the dense side (plain Newton from there)
+                r_dense = true;
+                return;
+            }
+            double den = r_dense ? dp : dp - 4.0 * (p - r_pspec) * r_pk / (1.0 - r_rho * r_pk);
+            bool bad = !(dp > 0.0) || !(den > 0.0) || !is_finite_bits(p);
+            double step = (p - r_pspec) / den;
+            double rho_new = r_rho - step;
+            bad = bad || !(rho_new > 0.0) || !is_finite_bits(rho_new);
+            bool done = false;
+            if (!bad) {
+                double err = fabs(step) / r_rho;
+                done = err <= LIQ_ROOT_TOL || (r_it >= 3 && err < 1e-7 && err >= 0.25 * r_errprev);
+                r_errprev = err;
+                r_it++;
+                if (!done && r_it >= LIQ_ROOT_MAX_IT) bad = true;
+            }
+            if (bad) {
+                if (r_has_alt) {  // second choice of the specified pressure
+                    PCS_SM_START_ROOT(r_for, r_x0, r_x1, r_palt, false, 0.0);
+                } else if (r_for == R_PURE0 || r_for == R_PURE1) {
+                    // no Raoult estimate: start the substitution from the vapour composition at the caller's pressure
+                    p0 = p_init; x0 = z0; x1 = z1;
+                    PCS_SM_START_ROOT(R_SS, x0, x1, 0.0, true, p0);
+                } else {
+                    stage = S_DONE;  // rc = BD_FAILED
+                }
+                return;
+            }
+            if (!done) { r_rho = rho_new; return; }
+            // converged: chemical potentials carried to the root to first order
+            const double g0c = e.g0 - (r_x0 * e.h00 + r_x1 * e.h01) * step;
+            const double g1c = e.g1 - (r_x0 * e.h01 + r_x1 * e.h11) * step;
+            if (r_for == R_PURE0) {
+                f0 = rho_new * exp(g0c);
+                PCS_SM_START_ROOT(R_PURE1, 0.0, 1.0, 0.0, false, 0.0);
+                return;
+            }
+            if (r_for == R_PURE1) {
+                const double f1 = rho_new * exp(g1c);
+                p0 = 1.0 / (z0 / f0 + z1 / f1);  // Raoult
+                x0 = z0 * p0 / f0;
+                x1 = z1 * p0 / f1;
+                PCS_SM_START_ROOT(R_SS, x0, x1, 0.0, true, p0);
+                return;
+            }
+            if (r_for == R_BUBBLE) {
+                rs = rho_new;
+                ri0 = (z0 * rs) * exp(g0c);  // ideal vapour at the liquid's fugacities
+                ri1 = (z1 * rs) * exp(g1c);
+                stage = S_NEWTON_S;
+                return;
+            }
+            // R_SS: this evaluation (one tiny step away from the root) serves as the sweep's evaluation
+            rl = r_rho;
+            stage = S_SS;
+        }
+
+        if (stage == S_SS) {
+            double p = e.p(), dp = x0 * e.dp0() + x1 * e.dp1();
+            double drho = -p / dp;
+            const bool fine = (dp > 0.0) && is_finite_bits(p);
+            if (!(fine && fabs(drho) <= 0.05 * rl)) {
+                if (!resolved) {  // composition moved a lot: re-solve the liquid root here, then redo the sweep
+                    resolved = true;
+                    PCS_SM_START_ROOT(R_SS, x0, x1, 0.0, true, p0);
+                    return;
+                }
+                if (!fine) { stage = S_DONE; return; }
+                drho = 0.0;
+            }
+            resolved = false;
+            const double rlc = rl + drho;
+            const double w0 = z0 / (rlc * exp(e.g0 + (x0 * e.h00 + x1 * e.h01) * drho));
+            const double w1 = z1 / (rlc * exp(e.g1 + (x0 * e.h01 + x1 * e.h11) * drho));
+            rl = rlc;
+            const double sum = w0 + w1;
+            double n0 = w0 / sum, n1 = w1 / sum;
+            const double dx = fabs(n0 - x0);
+            const double xi = log(x0 / x1);
+            const double res = log(n0 / n1) - xi;
+            bool secant = false;
+            if (ss > 0 && xi != xi_prev) {
+                const double slope = (res - res_prev) / (xi - xi_prev);
+                if (slope < -0.05) {
+                    const double dxi = fmin(fmax(-res / slope, -1.6), 1.6);
+                    const double ee = exp(xi + dxi);
+                    x0 = ee / (1.0 + ee);
+                    x1 = 1.0 / (1.0 + ee);
+                    secant = true;
+                }
+            }
+            xi_prev = xi;
+            res_prev = res;
+            if (!secant) {
+                n0 = fmin(fmax(n0, 0.2 * x0), 5.0 * x0);
+                n1 = fmin(fmax(n1, 0.2 * x1), 5.0 * x1);
+                const double s2 = n0 + n1;
+                x0 = n0 / s2;
+                x1 = n1 / s2;
+            }
+            p0 = 1.0 / sum;
+            ss++;
+            const bool settled = dx < SS_TOL;
+            if (settled || ss >= ss_max) {
+                if (!settled && ss_max < SS_MAX_IT) { rc = BD_CAP; stage = S_DONE; return; }
+                ri0 = x0 * rl;
+                ri1 = x1 * rl;
+                rs = p0;
+                stage = S_NEWTON_S;
+            }
+            return;
+        }
+
+        if (stage == S_NEWTON_S || stage == S_FINAL_S) {
+            sv = e;
+            stage = (stage == S_NEWTON_S) ? S_NEWTON_N : S_FINAL_N;
+            return;
+        }
+
+        if (stage == S_NEWTON_N) {
+            const PhaseEval& s = sv;
+            const PhaseEval& n = e;
+            double A[3][4];
+            A[0][0] = rs * (z0 * (1.0 / s.r0 + s.h00) + z1 * s.h01);
+            A[1][0] = rs * (z0 * s.h01 + z1 * (1.0 / s.r1 + s.h11));
+            A[2][0] = rs * (z0 * s.dp0() + z1 * s.dp1());
+            A[0][1] = -ri0 * (1.0 / ri0 + n.h00);
+            A[1][1] = -ri0 * n.h01;
+            A[2][1] = -ri0 * n.dp0();
+            A[0][2] = -ri1 * n.h01;
+            A[1][2] = -ri1 * (1.0 / ri1 + n.h11);
+            A[2][2] = -ri1 * n.dp1();
+            A[0][3] = -(s.mu0() - n.mu0());
+            A[1][3] = -(s.mu1() - n.mu1());
+            A[2][3] = -(s.p() - n.p());
+            double du[3];
+            if (!solve3(A, du)) { stage = S_DONE; return; }
+            const double mx = fmax(fabs(du[0]), fmax(fabs(du[1]), fabs(du[2])));
+            if (!is_finite_bits(mx)) { stage = S_DONE; return; }
+            if (mx < err_best) { err_best = mx; it_best = it; }
+            else if (it - it_best >= NEWTON_NO_PROGRESS) { stage = S_DONE; return; }
+            const double scale = mx > 1.0 ? 1.0 / mx : 1.0;
+            rs *= exp(scale * du[0]);
+            ri0 *= exp(scale * du[1]);
+            ri1 *= exp(scale * du[2]);
+            out.iters = it + 1;
+            const bool stagnated = it >= 3 && mx < 1e-7 && mx >= 0.25 * err_prev;
+            err_prev = mx;
+            it++;
+            if (mx <= 1e-9 || stagnated) {
+                const double dens_i = ri0 + ri1;
+                const double lo = DEW ? rs : dens_i, hi = DEW ? dens_i : rs;
+                if (!(lo < hi * (1.0 - 1e-6))) { stage = S_DONE; return; }  // trivial solution
+                stage = S_FINAL_S;
+            } else if (it >= newton_max) {
+                rc = (newton_max < NEWTON_MAX_IT) ? BD_CAP : BD_FAILED;
+                stage = S_DONE;
+            } else {
+                stage = S_NEWTON_S;
+            }
+            return;
+        }
+
+        // S_FINAL_N: both phases evaluated at the converged state -> reference formula
+        out.spec0 = sv.r0; out.spec1 = sv.r1; out.inc0 = ri0; out.inc1 = ri1;
+        out.p = bubble_dew_formula(sv, e);
+        rc = is_finite_bits(out.p) ? BD_OK : BD_FAILED;
+        stage = S_DONE;
+#undef PCS_SM_START_ROOT
+    }
+};
+
+// One row per lane: every pass of the wave-level loop evaluates once for every unfinished lane.
+template <bool DEW, class Model>
+PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
+                                int newton_max = NEWTON_MAX_IT) {
+    BdLane<DEW> L;
+    L.start(m, z0, p_init, ss_max, newton_max);
+    // worst case: 2 pure roots + (SS_MAX_IT sweeps each with a double root re-solve) + 2 evaluations per Newton iteration
+    constexpr int GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MAX_IT + 2) + 2 * NEWTON_MAX_IT + 8;
+    for (int guard = 0; guard < GUARD; guard++) {
+        if (__ballot(!L.done()) == 0ull) break;
+        if (L.done()) continue;
+        double e0, e1;
+        L.point(e0, e1);
+        PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
+        L.consume(m, e);
+    }
+    out = L.out;
+    return L.done() ? L.rc : BD_FAILED;
+}
+
+}  // namespace pcs

@@ -33,7 +33,8 @@ int pcs_abi_version(void);
 /* Last error message of the calling thread ("" if none). */
 const char* pcs_last_error(void);
 
-/* Bytes of device scratch a call on n rows needs (retry list for the robust pass). */
+/* Bytes of device scratch a call on n rows needs (retry list of the pure / gc robust pass, or row order +
+ * control block of the mixture work queue). */
 int64_t pcs_workspace_bytes(int64_t n);
 
 /*
@@ -113,9 +114,9 @@ int pcs_pure_jacobian(int which, const double* params, const double* temp, const
  *   rho4    [n,4]   out   A^-3 (rhoV_1, rhoV_2, rhoL_1, rhoL_2), src/pcsaft.rs:225-228 (optional)
  *   status  [n]     out   uint8, 1 = failed
  *   iters   [n]     out   int32 Newton iterations (optional)
- *   workspace       device scratch of pcs_workspace_bytes(n) for the two-pass schedule (fast pass with
- *                   small iteration caps + robust pass over the compacted slow rows); NULL = one pass
- *                   with the full caps (same results, slower)
+ *   workspace       device scratch of pcs_workspace_bytes(n) for the work-queue schedule (rows ordered by
+ *                   class on the device, persistent waves, a lane that finishes a row takes the next one);
+ *                   NULL = one row per lane in a single pass (same results, several times slower)
  */
 int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const double* temp, const double* z,
                        const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status, int32_t* iters,
