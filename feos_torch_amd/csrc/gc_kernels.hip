@@ -66,6 +66,8 @@ __device__ __forceinline__ void gc_store(int64_t i, int rc, const MixResult& r, 
     status[i] = ok ? 0 : 1;
 }
 
+// (A work-queue schedule as in mix_kernels.hip was measured here too: the gc rows need nearly the same number of
+// evaluations each, so it only adds the refill overhead: bubble 4.1 -> 4.7 ms, dew 12.4 -> 15.3 ms per 1e6 rows.)
 // K7.  RETRY = false: fast pass over all rows (small caps, cap hits appended to the retry list;
 // retry == nullptr -> full caps, single pass).  RETRY = true: robust pass, grid-stride over the list.
 template <bool DEW, bool RETRY>
