@@ -16,7 +16,10 @@
 namespace pcs {
 
 constexpr int MIX_DIRS = 19;  // 16 parameters (component 0 then 1), k_ij, eps_AiBj, T
-constexpr int MIX_CHUNK = 2;
+#ifndef PCS_MIX_CHUNK
+#define PCS_MIX_CHUNK 1  // directions per pass; A/B on 1e6 rows: 1: 35 ms, 2: 41, 3: 47, 4: 54 (register pressure)
+#endif
+constexpr int MIX_CHUNK = PCS_MIX_CHUNK;
 
 struct MixModelD {
     MixCoef<double> c;
@@ -24,12 +27,17 @@ struct MixModelD {
     PCS_DEV double packing(double x0, double x1) const { return x0 * c.zk[3][0] + x1 * c.zk[3][1]; }
 };
 
+template <class G, class R>
+__device__ __attribute__((noinline)) R mix_a_tangent(const MixCoef<G>& c, const R& r0, const R& r1) {
+    return mix_a<G, R>(c, r0, r1);
+}
+
 // spec = (rho_spec_0, rho_spec_1), inc = (rho_inc_0, rho_inc_1); out[19] in Pa per unit of theta
 // spec_is_vapor: the pressure functional is always taken on the VAPOUR phase (p^S for dew, p^I for
 // bubble): the liquid-phase pressure is a difference of O(0.1) terms, so its explicit parameter
 // derivative would have to cancel against w . dF/dtheta to the size of p itself.
 PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, double s0, double s1, double i0,
-                          double i1, bool spec_is_vapor, double g[MIX_DIRS]) {
+                          double i1, bool spec_is_vapor, double* __restrict__ g) {
     MixModelD m;
     mix_coef<double>(m.c, par, k0, k1, T);
     PhaseEval s = phase_eval(m, s0, s1);
@@ -65,9 +73,23 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
     typedef DN<double, MIX_CHUNK> G;
     typedef T1<G> R;
     constexpr int NPASS = (MIX_DIRS + MIX_CHUNK - 1) / MIX_CHUNK;
+    // directions whose derivative is structurally zero: a dipole moment of 0 (the term is quadratic in it), every
+    // association parameter when no component associates (the term is absent), eps_AiBj unless it is in use
+    const bool no_assoc = m.c.acls == ASSOC_NONE;
+    const bool eab_used = m.c.acls == ASSOC_CROSS && k1 != 0.0;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; pass++) {
         const int d0 = pass * MIX_CHUNK;
+        if (MIX_CHUNK == 1) {
+            const int kk = d0 & 7;
+            bool zero = false;
+            if (d0 < 16) zero = (kk == 3 && par[d0] == 0.0) || (kk >= 4 && no_assoc);
+            else if (d0 == 17) zero = !eab_used;
+            if (__ballot(!zero) == 0ull) {  // the whole wave skips the pass
+                g[d0] = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
+                continue;
+            }
+        }
         G gp[16], gk0, gk1, gT;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -84,21 +106,31 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
         }
         MixCoef<G> c;
         mix_coef<G>(c, gp, gk0, gk1, gT);
-        R aS = mix_a<G, R>(c, R(G(s0), G(1.0), G(0.0)), R(G(s1), G(0.0), G(1.0)));
-        R aI = mix_a<G, R>(c, R(G(i0), G(1.0), G(0.0)), R(G(i1), G(0.0), G(1.0)));
+        // both phases through ONE evaluation site (loop not unrolled, evaluation not inlined): the dual-number
+        // evaluation is large, two inlined copies per pass cost ~5,000 spilled VGPRs
+        double av[2][MIX_CHUNK], ag0[2][MIX_CHUNK], ag1[2][MIX_CHUNK];
+#pragma unroll 1
+        for (int ph = 0; ph < 2; ph++) {
+            const double q0 = ph == 0 ? s0 : i0, q1 = ph == 0 ? s1 : i1;
+            R a = mix_a_tangent<G, R>(c, R(G(q0), G(1.0), G(0.0)), R(G(q1), G(0.0), G(1.0)));
+#pragma unroll
+            for (int j = 0; j < MIX_CHUNK; j++) {
+                const double v = a.v.e[j], d0v = a.g0.e[j], d1v = a.g1.e[j];
+                if (ph == 0) { av[0][j] = v; ag0[0][j] = d0v; ag1[0][j] = d1v; }
+                else { av[1][j] = v; ag0[1][j] = d0v; ag1[1][j] = d1v; }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < MIX_CHUNK; j++) {
-            double dF0 = aS.g0.e[j] - aI.g0.e[j];
-            double dF1 = aS.g1.e[j] - aI.g1.e[j];
-            double dpS = -aS.v.e[j] + s0 * aS.g0.e[j] + s1 * aS.g1.e[j];
-            double dpI = -aI.v.e[j] + i0 * aI.g0.e[j] + i1 * aI.g1.e[j];
+            double dF0 = ag0[0][j] - ag0[1][j];
+            double dF1 = ag1[0][j] - ag1[1][j];
+            double dpS = -av[0][j] + s0 * ag0[0][j] + s1 * ag1[0][j];
+            double dpI = -av[1][j] + i0 * ag0[1][j] + i1 * ag1[1][j];
             double dp = (spec_is_vapor ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
             double val = dp * T * P_UNIT;
             if (d0 + j == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
             if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
-#pragma unroll
-            for (int d = 0; d < MIX_DIRS; d++)
-                if (d == d0 + j) g[d] = val;
+            if (d0 + j < MIX_DIRS) g[d0 + j] = val;
         }
     }
 }

@@ -355,16 +355,38 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* 
                                                          const double* __restrict__ temp,
                                                          const double* __restrict__ rho4, int64_t n,
                                                          double* __restrict__ jac) {
-    const int64_t i = (int64_t)blockIdx.x * MBLOCK + threadIdx.x;
+    // rows of the workgroup bucketed by class as in k_mix_bubble_dew: waves of non-associating rows skip the
+    // association directions altogether
+    __shared__ int perm[MBLOCK];
+    __shared__ int bins[MIX_BINS + 1];
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * MBLOCK;
+    if (t <= MIX_BINS) bins[t] = 0;
+    __syncthreads();
+    int key = MIX_BINS;
+    if (row0 + t < n) key = mix_bucket(params + 16 * (row0 + t));
+    atomicAdd(&bins[key], 1);
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+#pragma unroll
+        for (int b = 0; b <= MIX_BINS; b++) {
+            int c = bins[b];
+            bins[b] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+    perm[atomicAdd(&bins[key], 1)] = t;
+    __syncthreads();
+    const int64_t i = row0 + perm[t];
     if (i >= n) return;
     double par[16], k0, k1;
     load_mix_row(params, kij, i, par, k0, k1);
     double4 r = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
-    double g[MIX_DIRS];
+    double* g = jac + MIX_DIRS * i;
     if (dew) mix_jacobian(par, k0, k1, temp[i], r.x, r.y, r.z, r.w, true, g);
     else mix_jacobian(par, k0, k1, temp[i], r.z, r.w, r.x, r.y, false, g);
-#pragma unroll
-    for (int k = 0; k < MIX_DIRS; k++) jac[MIX_DIRS * i + k] = g[k];
 }
 
 // resident waves of the queue kernel: one per SIMD (the evaluation needs the whole register file)
