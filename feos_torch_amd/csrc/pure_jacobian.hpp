@@ -13,14 +13,17 @@
 namespace pcs {
 
 constexpr int JAC_DIRS = 10;  // 8 parameters, T, p
-constexpr int JAC_CHUNK = 2;  // directions per pass
+#ifndef PCS_JAC_CHUNK
+#define PCS_JAC_CHUNK 2
+#endif
+constexpr int JAC_CHUNK = PCS_JAC_CHUNK;  // directions per pass
 
 // WHICH: 0 vapor_pressure [Pa], 1 liquid_density [kmol/m3], 2 equilibrium_liquid_density [kmol/m3]
 template <int WHICH>
 PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv, double rl, double g[JAC_DIRS]) {
     typedef DN<double, JAC_CHUNK> G;
     typedef D2<G> R;
-    constexpr int NPASS = (WHICH == 1) ? 5 : 5;  // direction 9 (p) is non-zero only for WHICH == 1
+    constexpr int NPASS = (JAC_DIRS + JAC_CHUNK - 1) / JAC_CHUNK;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; pass++) {
         const int d0 = pass * JAC_CHUNK;
@@ -70,7 +73,7 @@ PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv
         for (int d = 0; d < JAC_DIRS; d++) {
 #pragma unroll
             for (int j = 0; j < JAC_CHUNK; j++)
-                if (d == d0 + j) g[d] = val.e[j];
+                if (d == d0 + j && d < JAC_DIRS) g[d] = val.e[j];
         }
     }
 }
