@@ -13,6 +13,9 @@
 
 namespace pcs {
 
+#ifndef PCS_F32_VIRIAL
+#define PCS_F32_VIRIAL 1
+#endif
 #ifndef PCS_F32_PREDICT_STOP
 #define PCS_F32_PREDICT_STOP 1  // stop the fp32 iteration when the PREDICTED next step (quadratic convergence) is below the fp32 noise floor
 #endif
@@ -203,6 +206,24 @@ PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double&
 #endif
     EvalF l = pure_eval_f32(f, rl);
     float rv = rl * __expf(l.mu);
+#if PCS_F32_VIRIAL
+    {
+        // second-virial correction of the ideal-gas estimate: ln rho + 2 B rho = ln rho_L + mu_L^res with
+        // B = lim a/rho^2 from the coefficients (no model evaluation); three scalar Newton steps
+        float B = (4.0f * f.m - 2.5f * f.mm1) * f.ceta + f.kd1 * f.ai[0] + f.kd2 * f.bi[0];
+        if (f.polar) B += f.qm * f.j1[0];
+        if (f.assoc) B -= f.na * f.nb * f.da;
+        const float Lg = __logf(rv);
+        float r = rv;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float den = fmaxf(1.0f + 2.0f * B * r, 0.3f);
+            float fr = __logf(r) + 2.0f * B * r - Lg;
+            r = r * fmaxf(1.0f - fr * __builtin_amdgcn_rcpf(den), 0.2f);
+        }
+        if (finitef(r) && r > 0.0f) rv = r;
+    }
+#endif
     if (diag) code = !ok ? 1 : !done ? 5 : !finitef(rv) ? 6 : !(l.dp > 0.0f) ? 7 : !(rv < 0.5f * rl) ? 8 : !(rv > 1e-30f) ? 9 : 0;
     ok = ok && done && finitef(rv) && (l.dp > 0.0f) && (rv < 0.5f * rl) && (rv > 1e-30f);
     // coupled Newton towards the equal-area pressure, to the fp32 noise floor
