@@ -100,6 +100,33 @@ template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator-(const D2<T>& a, const 
 template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator-(const T& b, const D2<T>& a) { return D2<T>(b - a.v, -a.d1, -a.d2); }
 
 // =========================================================================================
+// D1s: value + first derivative along one direction, plain doubles (the solver's fp64 finish, which takes the
+// second derivative from the fp32 pre-solve).  Uses the same d_recip(double) as D2<double>.
+// =========================================================================================
+struct D1s {
+    double v, d1;
+    PCS_DEV D1s() {}
+    PCS_DEV D1s(double x) : v(x), d1(0.0) {}
+    PCS_DEV D1s(double a, double b) : v(a), d1(b) {}
+    PCS_DEV D1s chain(double f0, double f1) const { return D1s(f0, f1 * d1); }
+};
+template <> struct is_dual<D1s> { static constexpr bool value = true; };
+PCS_DEV double re(const D1s& a) { return a.v; }
+PCS_DEV D1s operator+(const D1s& a, const D1s& b) { return D1s(a.v + b.v, a.d1 + b.d1); }
+PCS_DEV D1s operator-(const D1s& a, const D1s& b) { return D1s(a.v - b.v, a.d1 - b.d1); }
+PCS_DEV D1s operator-(const D1s& a) { return D1s(-a.v, -a.d1); }
+PCS_DEV D1s operator*(const D1s& a, const D1s& b) { return D1s(a.v * b.v, a.d1 * b.v + a.v * b.d1); }
+PCS_DEV D1s operator+(const D1s& a, double b) { return D1s(a.v + b, a.d1); }
+PCS_DEV D1s operator+(double b, const D1s& a) { return D1s(a.v + b, a.d1); }
+PCS_DEV D1s operator-(const D1s& a, double b) { return D1s(a.v - b, a.d1); }
+PCS_DEV D1s operator-(double b, const D1s& a) { return D1s(b - a.v, -a.d1); }
+PCS_DEV D1s operator*(const D1s& a, double b) { return D1s(a.v * b, a.d1 * b); }
+PCS_DEV D1s operator*(double b, const D1s& a) { return D1s(a.v * b, a.d1 * b); }
+PCS_DEV D1s d_recip(const D1s& a) { double r = d_recip(a.v); return a.chain(r, -(r * r)); }
+PCS_DEV D1s d_log(const D1s& a) { return a.chain(d_log(a.v), d_recip(a.v)); }
+PCS_DEV D1s d_sqrt(const D1s& a) { double s = d_sqrt(a.v); return a.chain(s, 0.5 * d_recip(s)); }
+
+// =========================================================================================
 // DN<T,N>
 // =========================================================================================
 template <class T, int N>

@@ -193,7 +193,10 @@ PCS_DEV bool liquid_root_f32(const PureCoefF& f, float p_spec, float tol, float 
 
 // fp32 pass.  Returns true with (rl, rv) close to the solution (typically 1e-6 relative) when
 // every step of the pass behaved; false = this lane must use the fp64 initialiser.
-PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double& rv_out, int* diag = nullptr) {
+// dpl_out / dpv_out: dp/drho of the two phases from the pass's last evaluations (one small step before the
+// returned densities): the second derivative the fp64 finish uses for its Newton steps.
+PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double& rv_out, float& dpl_out, float& dpv_out,
+                              int* diag = nullptr) {
     int n_liq = 0, n_cpl = 0, code = 0;
     PureCoefF f;
     to_f32(c, f);
@@ -202,7 +205,7 @@ PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double&
     bool ok = liquid_root_f32(f, 0.0f, PCS_F32_LIQ_TOL, 1e-2f, 12, rl, n_liq);
     bool done = ok;
 #if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 2  // timing experiments only
-    rl_out = (double)rl; rv_out = ok ? 1.0 : 2.0; return ok;
+    rl_out = (double)rl; rv_out = ok ? 1.0 : 2.0; dpl_out = dpv_out = 1.0f; return ok;
 #endif
     EvalF l = pure_eval_f32(f, rl);
     float rv = rl * __expf(l.mu);
@@ -228,12 +231,14 @@ PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double&
     ok = ok && done && finitef(rv) && (l.dp > 0.0f) && (rv < 0.5f * rl) && (rv > 1e-30f);
     // coupled Newton towards the equal-area pressure, to the fp32 noise floor
     done = !ok;
+    float dpv_last = 1.0f;
 #if PCS_F32_PREDICT_STOP
     float sl_prev = 1.0f, sv_prev = 1.0f;
 #endif
     for (int it = 0; it < 8; it++) {
         if (!done) {
             EvalF v = pure_eval_f32(f, rv);
+            dpv_last = v.dp;
             n_cpl++;
             float iv = __builtin_amdgcn_rcpf(rv), il = __builtin_amdgcn_rcpf(rl);
             float ps = -(v.a * iv - l.a * il + __logf(rv * il)) * __builtin_amdgcn_rcpf(iv - il);
@@ -266,6 +271,8 @@ PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double&
     }
     rl_out = (double)rl;
     rv_out = (double)rv;
+    dpl_out = l.dp;
+    dpv_out = dpv_last;
     if (diag) *diag = n_liq | (n_cpl << 8) | (code << 16);  // diagnostics builds only
     return ok;  // not converged within the caps is fine: the fp64 iteration continues from here
 }

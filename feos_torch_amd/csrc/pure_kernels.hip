@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __re
     PureCoef<double> c;
     pure_coef<double>(c, par, T, false);
     VleResult res;
-    int st = rho_eq ? vle_fast(c, res, 1e-8, TOL_STEP) : vle_fast(c, res);  // wave-uniform
+    int st = rho_eq ? vle_fast<false>(c, res, 1e-8, TOL_STEP) : vle_fast<true>(c, res);  // wave-uniform
 
     if (!live) return;
     if (st == ST_OK) {

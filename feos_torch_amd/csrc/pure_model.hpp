@@ -116,6 +116,17 @@ template <int N, class P, class R>
 PCS_DEV R horner_eta(const P* coef, const R& x) { return horner<N>(coef, x); }
 template <int N>
 PCS_DEV D2<double> horner_eta(const double* coef, const D2<double>& x) { return horner_lin<N>(coef, x); }
+// value + first derivative: 2 FMA per coefficient
+template <int N>
+PCS_DEV D1s horner_eta(const double* coef, const D1s& x) {
+    double p = coef[N - 1], d1 = 0.0;
+#pragma unroll
+    for (int i = N - 2; i >= 0; i--) {
+        d1 = __builtin_fma(d1, x.v, p);
+        p = __builtin_fma(p, x.v, coef[i]);
+    }
+    return D1s(p, d1 * x.d1);
+}
 
 template <class R>
 PCS_DEV R site_term(const R& x) {  // ln x - x/2 + 1/2   (:176)

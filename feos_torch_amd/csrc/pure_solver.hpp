@@ -46,6 +46,9 @@ PCS_DEV Eval pure_eval_mu(const PureCoef<double>& c, double rho, double& mu_res)
     return e;
 }
 
+#ifndef PCS_LITE_FINISH
+#define PCS_LITE_FINISH 1
+#endif
 constexpr int LIQ_MAX_IT = 40;
 constexpr int VLE_MAX_IT = 40;
 constexpr double ETA_START = 0.5;
@@ -162,17 +165,22 @@ PCS_DEV VleStep vle_step(const Eval& l, const Eval& v, double rl, double rv) {
 // tol_l: relative liquid step at which a lane stops.  TOL_STEP suffices for the pressure (second-order
 // corrected); the saturated liquid density itself is only as good as the last step squared, so the
 // caller passes a tighter value when that output is requested.
+// LITE (pressure-only output): when every lane of the wave has an fp32 pre-solve, the fp64 finish evaluates only
+// a and a' in fp64 (D1s) and takes dp/drho for its Newton steps and for the second-order term of p* from the
+// fp32 pass -- the Jacobian only steers the step (error ~1e-3 of a ~1e-6 step), the residuals and p* are fp64.
+template <bool LITE>
 PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
     double rl = 0.0, rv = 0.0;
     Eval l;
     bool warm = false;
+    float dpl32 = 1.0f, dpv32 = 1.0f;
 #ifdef PCS_F32_PRESOLVE
 #ifdef PCS_DIAG_ITERS
     int diag = 0;
-    warm = vle_presolve_f32(c, rl, rv, &diag);
+    warm = vle_presolve_f32(c, rl, rv, dpl32, dpv32, &diag);
 #else
 #if !(defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 1)
-    warm = vle_presolve_f32(c, rl, rv);  // fp32 initialiser + first iterations (pure_f32.hpp)
+    warm = vle_presolve_f32(c, rl, rv, dpl32, dpv32);  // fp32 initialiser + first iterations (pure_f32.hpp)
 #endif
 #endif
 #endif
@@ -184,6 +192,45 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = T
         for (int i = 0; i < 4; i++) acc += c.j2[i];
         out.p_star = acc; out.rho_l = rl; out.rho_v = rv; out.iters = 0;
         return ST_OK;
+    }
+#endif
+#if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
+    if (LITE && __ballot(!warm) == 0ull) {
+        bool active = is_finite_bits(rv) && (rv < 0.7 * rl) && (dpl32 > 0.0f) && (dpv32 > 0.0f);
+        bool done = false;
+        out.iters = 0;
+        Eval le, ve;
+        le.dp = (double)dpl32;
+        ve.dp = (double)dpv32;
+        for (int it = 0; it < VLE_MAX_IT; it++) {
+            if (active && !done) {
+                D1s al = pure_a<double, D1s>(c, D1s(rl, 1.0));
+                D1s av = pure_a<double, D1s>(c, D1s(rv, 1.0));
+                le.a = al.v; le.p = rl - al.v + rl * al.d1;
+                ve.a = av.v; ve.p = rv - av.v + rv * av.d1;
+                VleStep s = vle_step(le, ve, rl, rv);
+                bool ok = is_finite_bits(s.p_star) && is_finite_bits(s.dl) && is_finite_bits(s.dv);
+                double rl_new = rl + s.dl, rv_new = rv + s.dv;
+                ok = ok && (rl_new > 0.0) && (rv_new > 0.0) && (rv_new < rl_new);
+                if (!ok) {
+                    active = false;
+                } else {
+                    done = (fabs(s.dl) <= tol_l * rl) && (fabs(s.dv) <= tol_v * rv);
+                    rl = rl_new;
+                    rv = rv_new;
+                    out.rho_v = rv;
+                    out.rho_l = rl;
+                    out.p_star = s.p_corr;
+                    out.iters = it + 1;
+                }
+            }
+            if (__ballot(active && !done) == 0ull) break;
+        }
+#if defined(PCS_DIAG_ITERS)
+        out.iters |= diag << 8;
+#endif
+        if (done && out.rho_v < 0.7 * out.rho_l) return ST_OK;
+        return ST_RETRY;
     }
 #endif
     bool active = warm;
