@@ -95,6 +95,56 @@ PCS_DEV void to_f32(const PureCoef<double>& c, PureCoefF& f) {
     f.da = (float)c.da; f.na = (float)c.na; f.nb = (float)c.nb;
 }
 
+// Native fp32 version of pure_coef() (pure_model.hpp): the pre-solve needs its coefficients to ~1e-6 only, and
+// computing them from the fp32 parameters keeps the 33 fp64 coefficients out of the registers until the fp64
+// finish needs them.
+PCS_DEV void pure_coef_f32(PureCoefF& f, const double* par, double T64) {
+    const float m = (float)par[0], sigma = (float)par[1], eps = (float)par[2], mu = (float)par[3];
+    const float rT = __builtin_amdgcn_rcpf((float)T64);
+    const float s3 = sigma * sigma * sigma;
+    const float e = eps * rT;
+    const float d = sigma * (1.0f - 0.12f * __expf(-3.0f * e));
+    f.m = m;
+    f.mm1 = m - 1.0f;
+    f.ceta = (float)FRAC_PI_6 * (m * (d * d * d));
+    const float rm = __builtin_amdgcn_rcpf(m);
+    const float m1 = f.mm1 * rm;
+    const float m2 = (m - 2.0f) * rm;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        f.ai[i] = fmaf(m1, fmaf(m2, (float)A2[i], (float)A1[i]), (float)A0[i]);
+        f.bi[i] = fmaf(m1, fmaf(m2, (float)B2[i], (float)B1[i]), (float)B0[i]);
+    }
+    const float pref = (float)(-PI) * ((m * m) * (e * s3));
+    f.kd1 = 2.0f * pref;
+    f.kd2 = pref * (m * e);
+    f.polar = mu != 0.0f;
+    f.qm = 0.0f;
+    if (f.polar) {
+        const float mu2t = (mu * mu) * (rm * rT) * (float)MU2_UNIT;
+        const bool clamp = m > 2.0f;
+        const float md1 = clamp ? 0.5f : m1;
+        const float md2 = clamp ? 0.0f : md1 * m2;
+        const float rs3 = __builtin_amdgcn_rcpf(s3);
+        const float f2c = (float)(-PI) * rs3;
+        const float f3c = (float)(-PI_SQ_43) * (rs3 * mu2t);
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            float a = (float)AD[i][0] + md1 * (float)AD[i][1] + md2 * (float)AD[i][2];
+            if (i < 3) a = a + ((float)BD[i][0] + md1 * (float)BD[i][1] + md2 * (float)BD[i][2]) * e;
+            f.j1[i] = a * f2c;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) f.j2[i] = ((float)CD[i][0] + md1 * (float)CD[i][1] + md2 * (float)CD[i][2]) * f3c;
+        f.qm = mu2t * mu2t;
+    }
+    f.na = (float)par[6];
+    f.nb = (float)par[7];
+    const bool sites = (f.na != 0.0f) || (f.nb != 0.0f);
+    f.da = (__expf((float)par[5] * rT) - 1.0f) * s3 * (float)par[4];
+    f.assoc = sites && f.da != 0.0f;
+}
+
 struct EvalF { float a, p, dp, mu; };
 
 // same model as pure_a() (pure_model.hpp), fp32
@@ -195,11 +245,9 @@ PCS_DEV bool liquid_root_f32(const PureCoefF& f, float p_spec, float tol, float 
 // every step of the pass behaved; false = this lane must use the fp64 initialiser.
 // dpl_out / dpv_out: dp/drho of the two phases from the pass's last evaluations (one small step before the
 // returned densities): the second derivative the fp64 finish uses for its Newton steps.
-PCS_DEV bool vle_presolve_f32(const PureCoef<double>& c, double& rl_out, double& rv_out, float& dpl_out, float& dpv_out,
+PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out, float& dpl_out, float& dpv_out,
                               int* diag = nullptr) {
     int n_liq = 0, n_cpl = 0, code = 0;
-    PureCoefF f;
-    to_f32(c, f);
     // zero-pressure liquid, handed over to the coupled iteration at a loose step
     float rl;
     bool ok = liquid_root_f32(f, 0.0f, PCS_F32_LIQ_TOL, 1e-2f, 12, rl, n_liq);

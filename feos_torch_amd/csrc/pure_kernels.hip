@@ -79,6 +79,9 @@ __device__ __forceinline__ int k1_bucket(const double* row) {
 // irrelevant) and lane t solves the row at sorted position t.  A larger bucketing domain (4 tiles per
 // workgroup) measured only 2-3 % faster and costs either LDS occupancy or a non-inlined call per
 // tile whose callee-saved registers go through scratch (3.8 GB of HBM writes per 1e7 rows): not used.
+// LITE (pressure-only output, fp32 pre-solve available): vle_fast_lite; rows without a usable fp32 result are
+// appended with bit 31 set (k_pure_vle_fallback takes them), rows for the robust pass without.
+template <bool LITE>
 __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __restrict__ params,
                                                     const double* __restrict__ temp, int64_t n,
                                                     double* __restrict__ p_sat, double* __restrict__ rho_eq,
@@ -132,10 +135,13 @@ __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __re
     for (int q = 0; q < 8; q++) par[q] = lds[r * ROW_PAD + q];
     const double T = lds[r * ROW_PAD + 8];
 
-    PureCoef<double> c;
-    pure_coef<double>(c, par, T, false);
     VleResult res;
-    int st = rho_eq ? vle_fast<false>(c, res, 1e-8, TOL_STEP) : vle_fast<true>(c, res);  // wave-uniform
+    int st;  // wave-uniform calls
+#if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
+    if (LITE) st = vle_fast_lite(par, T, res);
+    else
+#endif
+        st = rho_eq ? vle_fast(par, T, res, 1e-8, TOL_STEP) : vle_fast(par, T, res);
 
     if (!live) return;
     if (st == ST_OK) {
@@ -148,9 +154,41 @@ __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __re
         if (iters) iters[i] = res.iters;
         status[i] = 0;
     } else {
-        status[i] = 1;  // provisional; the robust pass overwrites it
+        status[i] = 1;  // provisional; a later pass overwrites it
         int slot = atomicAdd(&retry[0], 1);
-        retry[1 + slot] = (int32_t)i;  // n < 2^31 checked on the host
+        retry[1 + slot] = (int32_t)((uint32_t)i | (st == ST_FALLBACK ? 0x80000000u : 0u));  // n < 2^31 checked on the host
+    }
+}
+
+// Rows of the list with bit 31 set (no usable fp32 pre-solve): the all-fp64 fast path.  Solved rows keep the
+// bit (the robust pass skips them), rows that need the robust pass get it cleared.
+constexpr int FALLBACK_GRID = 1024;
+__global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restrict__ params, const double* __restrict__ temp,
+                                                          double* __restrict__ p_sat, double* __restrict__ rho_vl,
+                                                          uint8_t* __restrict__ status, int32_t* __restrict__ iters,
+                                                          int32_t* __restrict__ retry) {
+    const int count = retry[0];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const uint32_t entry = (uint32_t)retry[1 + k];
+        if (!(entry & 0x80000000u)) continue;
+        const int64_t i = (int64_t)(entry & 0x7fffffffu);
+        double par[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) par[j] = params[8 * i + j];
+        const double T = temp[i];
+        VleResult res;
+        int st = vle_fast(par, T, res);
+        if (st == ST_OK) {
+            if (p_sat) p_sat[i] = res.p_star * T * P_UNIT;
+            if (rho_vl) {
+                rho_vl[2 * i] = res.rho_v;
+                rho_vl[2 * i + 1] = res.rho_l;
+            }
+            if (iters) iters[i] = res.iters;
+            status[i] = 0;
+        } else {
+            retry[1 + k] = (int32_t)i;  // bit 31 cleared: robust pass
+        }
     }
 }
 
@@ -256,7 +294,20 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
     hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return fail("hipMemsetAsync", e);
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_pure_vle, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
+#if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
+    // LITE only for the pressure-only call: its densities are converged to ~1e-9 (enough for p*, whose error is of
+    // second order in them), while the Jacobian kernels want the ~1e-12 of the full path in rho_vl
+    if (!rho_eq && !rho_vl) {
+        hipLaunchKernelGGL(k_pure_vle<true>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
+                           iters, retry);
+        hipLaunchKernelGGL(k_pure_vle_fallback, dim3(FALLBACK_GRID), dim3(64), 0, s, params, temp, p_sat, rho_vl, status,
+                           iters, retry);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail("k_pure_vle launch", e);
+        return 0;
+    }
+#endif
+    hipLaunchKernelGGL(k_pure_vle<false>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                        iters, retry);
     e = hipGetLastError();
     if (e != hipSuccess) return fail("k_pure_vle launch", e);

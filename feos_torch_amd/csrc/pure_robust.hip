@@ -23,7 +23,9 @@ __global__ __launch_bounds__(64) void k_pure_vle_robust(const double* __restrict
                                                         const int32_t* __restrict__ retry) {
     const int count = retry[0];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-        const int64_t i = retry[1 + k];
+        const uint32_t entry = (uint32_t)retry[1 + k];
+        if (entry & 0x80000000u) continue;  // solved by k_pure_vle_fallback (pure_kernels.hip)
+        const int64_t i = (int64_t)entry;
         double par[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) par[j] = params[8 * i + j];

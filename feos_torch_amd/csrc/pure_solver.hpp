@@ -20,7 +20,7 @@
 
 namespace pcs {
 
-enum : int { ST_OK = 0, ST_FAILED = 1, ST_RETRY = 2 };
+enum : int { ST_OK = 0, ST_FAILED = 1, ST_RETRY = 2, ST_FALLBACK = 3 };
 
 struct Eval {
     double a, p, dp;  // a, p = rho - a + rho a', dp/drho = 1 + rho a''   (pcsaft_pure.py:182)
@@ -165,25 +165,27 @@ PCS_DEV VleStep vle_step(const Eval& l, const Eval& v, double rl, double rv) {
 // tol_l: relative liquid step at which a lane stops.  TOL_STEP suffices for the pressure (second-order
 // corrected); the saturated liquid density itself is only as good as the last step squared, so the
 // caller passes a tighter value when that output is requested.
-// LITE (pressure-only output): when every lane of the wave has an fp32 pre-solve, the fp64 finish evaluates only
-// a and a' in fp64 (D1s) and takes dp/drho for its Newton steps and for the second-order term of p* from the
-// fp32 pass -- the Jacobian only steers the step (error ~1e-3 of a ~1e-6 step), the residuals and p* are fp64.
-template <bool LITE>
-PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
+PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
     double rl = 0.0, rv = 0.0;
     Eval l;
     bool warm = false;
     float dpl32 = 1.0f, dpv32 = 1.0f;
 #ifdef PCS_F32_PRESOLVE
+    PureCoefF cf;
+    pure_coef_f32(cf, par, T);
+#endif
+#ifdef PCS_F32_PRESOLVE
 #ifdef PCS_DIAG_ITERS
     int diag = 0;
-    warm = vle_presolve_f32(c, rl, rv, dpl32, dpv32, &diag);
+    warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32, &diag);
 #else
 #if !(defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 1)
-    warm = vle_presolve_f32(c, rl, rv, dpl32, dpv32);  // fp32 initialiser + first iterations (pure_f32.hpp)
+    warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32);  // fp32 initialiser + first iterations (pure_f32.hpp)
 #endif
 #endif
 #endif
+    PureCoef<double> c;
+    pure_coef<double>(c, par, T, false);
 #if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT <= 3  // timing experiments only: stop after coef (1), fp32 liquid (2), fp32 pre-solve (3)
     {
         double acc = rl + rv + c.m + c.mm1 + c.ceta + c.kd1 + c.kd2 + c.da + c.na + c.nb + c.qm;
@@ -192,45 +194,6 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = T
         for (int i = 0; i < 4; i++) acc += c.j2[i];
         out.p_star = acc; out.rho_l = rl; out.rho_v = rv; out.iters = 0;
         return ST_OK;
-    }
-#endif
-#if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
-    if (LITE && __ballot(!warm) == 0ull) {
-        bool active = is_finite_bits(rv) && (rv < 0.7 * rl) && (dpl32 > 0.0f) && (dpv32 > 0.0f);
-        bool done = false;
-        out.iters = 0;
-        Eval le, ve;
-        le.dp = (double)dpl32;
-        ve.dp = (double)dpv32;
-        for (int it = 0; it < VLE_MAX_IT; it++) {
-            if (active && !done) {
-                D1s al = pure_a<double, D1s>(c, D1s(rl, 1.0));
-                D1s av = pure_a<double, D1s>(c, D1s(rv, 1.0));
-                le.a = al.v; le.p = rl - al.v + rl * al.d1;
-                ve.a = av.v; ve.p = rv - av.v + rv * av.d1;
-                VleStep s = vle_step(le, ve, rl, rv);
-                bool ok = is_finite_bits(s.p_star) && is_finite_bits(s.dl) && is_finite_bits(s.dv);
-                double rl_new = rl + s.dl, rv_new = rv + s.dv;
-                ok = ok && (rl_new > 0.0) && (rv_new > 0.0) && (rv_new < rl_new);
-                if (!ok) {
-                    active = false;
-                } else {
-                    done = (fabs(s.dl) <= tol_l * rl) && (fabs(s.dv) <= tol_v * rv);
-                    rl = rl_new;
-                    rv = rv_new;
-                    out.rho_v = rv;
-                    out.rho_l = rl;
-                    out.p_star = s.p_corr;
-                    out.iters = it + 1;
-                }
-            }
-            if (__ballot(active && !done) == 0ull) break;
-        }
-#if defined(PCS_DIAG_ITERS)
-        out.iters |= diag << 8;
-#endif
-        if (done && out.rho_v < 0.7 * out.rho_l) return ST_OK;
-        return ST_RETRY;
     }
 #endif
     bool active = warm;
@@ -286,6 +249,64 @@ PCS_DEV int vle_fast(const PureCoef<double>& c, VleResult& out, double tol_l = T
     if (done && out.rho_v < 0.7 * out.rho_l) return ST_OK;
     return ST_RETRY;  // includes cap hit and near-critical states: let the robust path decide
 }
+
+#ifdef PCS_F32_PRESOLVE
+// Pressure-only fast path: fp32 pre-solve, then an fp64 finish that evaluates only a and a' in fp64 (D1s) and
+// takes dp/drho for its Newton steps and for the second-order term of p* from the fp32 pass -- the Jacobian only
+// steers the step (error ~1e-3 of a ~1e-6 step); the residuals and p* are fp64.  Lanes without a usable fp32
+// result return ST_FALLBACK (the all-fp64 path runs on them in a separate small kernel, which keeps this one at
+// 162 VGPRs), lanes that fail afterwards ST_RETRY (robust pass).
+PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
+    double rl = 0.0, rv = 0.0;
+    float dpl32 = 1.0f, dpv32 = 1.0f;
+    PureCoefF cf;
+    pure_coef_f32(cf, par, T);
+#ifdef PCS_DIAG_ITERS
+    int diag = 0;
+    const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32, &diag);
+#else
+    const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32);
+#endif
+    PureCoef<double> c;
+    pure_coef<double>(c, par, T, false);
+    bool active = warm && is_finite_bits(rv) && (rv < 0.7 * rl) && (dpl32 > 0.0f) && (dpv32 > 0.0f);
+    bool done = false;
+    out.iters = 0;
+    Eval le, ve;
+    le.dp = (double)dpl32;
+    ve.dp = (double)dpv32;
+    for (int it = 0; it < VLE_MAX_IT; it++) {
+        if (active && !done) {
+            D1s al = pure_a<double, D1s>(c, D1s(rl, 1.0));
+            D1s av = pure_a<double, D1s>(c, D1s(rv, 1.0));
+            le.a = al.v; le.p = rl - al.v + rl * al.d1;
+            ve.a = av.v; ve.p = rv - av.v + rv * av.d1;
+            VleStep s = vle_step(le, ve, rl, rv);
+            bool ok = is_finite_bits(s.p_star) && is_finite_bits(s.dl) && is_finite_bits(s.dv);
+            double rl_new = rl + s.dl, rv_new = rv + s.dv;
+            ok = ok && (rl_new > 0.0) && (rv_new > 0.0) && (rv_new < rl_new);
+            if (!ok) {
+                active = false;
+            } else {
+                done = (fabs(s.dl) <= tol_l * rl) && (fabs(s.dv) <= tol_v * rv);
+                rl = rl_new;
+                rv = rv_new;
+                out.rho_v = rv;
+                out.rho_l = rl;
+                out.p_star = s.p_corr;
+                out.iters = it + 1;
+            }
+        }
+        if (__ballot(active && !done) == 0ull) break;
+    }
+#ifdef PCS_DIAG_ITERS
+    out.iters |= diag << 8;
+#endif
+    if (!warm) return ST_FALLBACK;
+    if (done && out.rho_v < 0.7 * out.rho_l) return ST_OK;
+    return ST_RETRY;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Robust path (rare rows: near-critical temperatures, strongly non-ideal vapour).  Lane-serial

@@ -37,8 +37,10 @@ def _prep(x, device, shape_tail=None):
     return x
 
 
-def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=False):
-    """Pure VLE on the GPU.  -> dict(p_sat [Pa], rho_eq [kmol/m3], rho_vl [n,2] A^-3, status bool, iters)"""
+def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=False, want_rho_vl=True):
+    """Pure VLE on the GPU.  -> dict(p_sat [Pa], rho_eq [kmol/m3], rho_vl [n,2] A^-3, status bool, iters).
+    want_rho_vl=False with want_rho_eq=False selects the pressure-only kernel (fp64 finish with the fp32
+    pre-solve's dp/drho; densities not returned)."""
     device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
     params = _prep(params, device, (8,))
     temperature = _prep(temperature, device)
@@ -49,7 +51,7 @@ def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=Fal
     with torch.cuda.device(device):
         p_sat = torch.empty(n, dtype=_F64, device=device) if want_p else None
         rho_eq = torch.empty(n, dtype=_F64, device=device) if want_rho_eq else None
-        rho_vl = torch.empty((n, 2), dtype=_F64, device=device)
+        rho_vl = torch.empty((n, 2), dtype=_F64, device=device) if want_rho_vl else None
         status = torch.empty(n, dtype=torch.uint8, device=device)
         iters = torch.empty(n, dtype=torch.int32, device=device) if want_iters else None
         ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)

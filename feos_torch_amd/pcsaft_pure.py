@@ -34,8 +34,10 @@ class _PureProperty(torch.autograd.Function):
             rho_vl = torch.stack([torch.zeros_like(r["rho_root"]), r["rho_root"]], dim=1)
         else:
             P = None
+            # the converged densities are only needed by the Jacobian kernel
             r = native.pure_vle(par, T, want_p=(which == "vapor_pressure"),
-                                want_rho_eq=(which == "equilibrium_liquid_density"))
+                                want_rho_eq=(which == "equilibrium_liquid_density"),
+                                want_rho_vl=any(ctx.needs_input_grad[1:4]))
             value = r["p_sat"] if which == "vapor_pressure" else r["rho_eq"]
             rho_vl = r["rho_vl"]
         nans = r["status"]
