@@ -136,6 +136,14 @@ struct VleResult {
     int iters;
 };
 
+// x > 0 that is false for NaN even when the compiler may assume there are no NaNs
+PCS_DEV bool gt0(double x) { return is_finite_bits(x) && x > 0.0; }
+
+// A saturated vapour has 0 < Z = p/(rho kT) <= 1 (attraction dominates below the critical temperature).  Strongly
+// polar parameter sets give the EOS a second van-der-Waals loop at liquid-like densities; an iteration that lands on
+// it returns an "equilibrium" between two dense states with a negative or enormous pressure, which this rejects.
+PCS_DEV bool vapour_is_physical(double p_star, double rho_v) { return gt0(p_star) && p_star <= 1.0001 * rho_v; }
+
 // One coupled Newton update from evaluations l, v at (rl, rv):
 //   p*  = -(f_V - f_L)/(v_V - v_L),  f = a/rho + ln rho          (== pcsaft_pure.py:214)
 //   rho_k <- rho_k - (p_k - p*)/p'_k   for both phases           (liquid: == pcsaft_pure.py:232)
@@ -246,7 +254,7 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
 #if defined(PCS_DIAG_ITERS) && defined(PCS_F32_PRESOLVE)
     out.iters |= diag << 8;
 #endif
-    if (done && out.rho_v < 0.7 * out.rho_l) return ST_OK;
+    if (done && out.rho_v < 0.7 * out.rho_l && vapour_is_physical(out.p_star, out.rho_v)) return ST_OK;
     return ST_RETRY;  // includes cap hit and near-critical states: let the robust path decide
 }
 
@@ -303,7 +311,7 @@ PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double to
     out.iters |= diag << 8;
 #endif
     if (!warm) return ST_FALLBACK;
-    if (done && out.rho_v < 0.7 * out.rho_l) return ST_OK;
+    if (done && out.rho_v < 0.7 * out.rho_l && vapour_is_physical(out.p_star, out.rho_v)) return ST_OK;
     return ST_RETRY;
 }
 #endif
@@ -312,8 +320,6 @@ PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double to
 // Robust path (rare rows: near-critical temperatures, strongly non-ideal vapour).  Lane-serial
 // bisections; no wave-uniform tricks needed because it runs on a compacted list of few rows.
 // ---------------------------------------------------------------------------------------------
-// x > 0 that is false for NaN even when the compiler may assume there are no NaNs
-PCS_DEV bool gt0(double x) { return is_finite_bits(x) && x > 0.0; }
 
 PCS_DEV double branch_solve(const PureCoef<double>& c, double p_spec, double lo, double hi, double rho) {
     for (int it = 0; it < 60; it++) {
@@ -433,6 +439,13 @@ PCS_DEV int vle_robust(const PureCoef<double>& c, VleResult& out, double tol_l =
         err_prev = err;
         if (!damped && (err <= TOL_STEP || stagnated)) {
             if (!(rv < rl * (1.0 - 1e-6))) return ST_FAILED;  // trivial solution
+            if (!vapour_is_physical(out.p_star, rv)) return ST_FAILED;
+            // the vapour root must lie on the branch that starts at zero density: no mechanically unstable state below it
+            double probe = rv;
+            for (int k = 0; k < 8; k++) {
+                probe *= 0.5;
+                if (!gt0(pure_eval(c, probe).dp)) return ST_FAILED;
+            }
             return ST_OK;
         }
     }

@@ -214,6 +214,31 @@ def test_full_batch_equilibrium_conditions(amd, oracle):
 # ------------------------------------------------------------------------------------------
 # edge cases
 # ------------------------------------------------------------------------------------------
+def test_robust_pass_on_ordinary_rows(amd, oracle):
+    """The robust pass (pcs_pure_vle_retry) normally sees only rows the fast kernel gave up on; run on ordinary rows
+    (the list is written by the host here) it must either match the oracle or report failure -- strongly polar rows
+    give the EOS a second loop at liquid-like densities on which an unchecked iteration finds spurious equilibria."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch
+
+    n = 100_000
+    P, T = pure_batch(n, seed=77)
+    Pd, Td = torch.from_numpy(P).cuda(), torch.from_numpy(T).cuda()
+    plan = native.PureVlePlan(n, Pd.device)
+    plan.status.fill_(1)
+    plan.p_sat.zero_()
+    plan.ws[0] = n
+    plan.ws[1:n + 1] = torch.arange(n, dtype=torch.int32, device=Pd.device)
+    plan.run_retry(Pd, Td)
+    torch.cuda.synchronize()
+    got, st = plan.p_sat.cpu().numpy(), plan.status.cpu().numpy().astype(bool)
+    want, sw = oracle.pure_vapor_pressure(P, T, prec=1)
+    both = ~st & ~sw
+    assert both.mean() > 0.999
+    assert np.max(np.abs(got[both] / want[both] - 1)) < 1e-9
+    assert np.all(got[~st] > 0)
+
+
 def test_empty_batch(amd):
     eos = amd.PcSaftPure(torch.zeros((0, 8), dtype=f64))
     nans, vp = eos.vapor_pressure(torch.zeros(0, dtype=f64))
