@@ -146,7 +146,8 @@ def main():
     # ---- per-kernel duration of k_pure_vle from the HIP events (this rank) --------------------
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))  # per chunk launch
     fails = sum(int(p.status.sum().item()) for p in plans)
-    retry_rows = sum(p.retry_count() for p in plans)
+    counts = [p.retry_count() for p in plans]
+    fallback_rows, retry_rows = sum(c[0] for c in counts), sum(c[1] for c in counts)
 
     if rank == 0:
         total = world * rows * args.steps
@@ -175,11 +176,12 @@ def main():
                 "parallelism": f"row-sharded x{world}" + (", all-gather(p_sat,status) overlapped" if gather else ", no data-path collective"),
                 "seed": 2026,
                 "failed_rows_rank0": fails,
+                "fp64_fallback_rows_rank0": fallback_rows,
                 "robust_pass_rows_rank0": retry_rows,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_pure_vle",
+                "kernel": "k_pure_vle<pressure-only> (+ k_pure_vle_fallback on the 0.04 % rows without an fp32 pre-solve)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

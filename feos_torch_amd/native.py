@@ -190,7 +190,11 @@ class PureVlePlan:
         _lib.check(self._L.pcs_pure_vle_retry(*self._args(params, temperature)), "pcs_pure_vle_retry")
 
     def retry_count(self):
-        return int(self.ws[0].item())
+        """Rows of the last run that left the main kernel: (all-fp64 fallback rows, robust-pass rows)."""
+        cnt = int(self.ws[0].item())
+        entries = self.ws[1:1 + cnt]
+        fallback = int((entries < 0).sum().item())  # bit 31 set
+        return fallback, cnt - fallback
 
 
 # ------------------------------------------------------------------------------------------

@@ -72,17 +72,17 @@ for k, c in allc.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         lines.append(f"| **HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024** | {hbm:.6g} |")
-        if "k_pure_vle(" in k:
+        if "k_pure_vle(" in k or "k_pure_vle<" in k:
             traffic = hbm
     if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
         lines.append(f"| VALU instructions per wave (= per state point) | {c['SQ_INSTS_VALU']/c['SQ_WAVES']:.1f} |")
-        if "k_pure_vle(" in k:
+        if "k_pure_vle(" in k or "k_pure_vle<" in k:
             valu_instr = c["SQ_INSTS_VALU"]
     if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         # SQ_ACTIVE_INST_* count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over 8 XCDs
         simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
         lines.append(f"| VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE/8) | {c['SQ_ACTIVE_INST_VALU']*4/simd_cycles:.3f} |")
-        if "k_pure_vle(" in k:
+        if "k_pure_vle(" in k or "k_pure_vle<" in k:
             valu_busy = c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 if traffic is not None:
