@@ -152,6 +152,25 @@ def test_phase_equilibrium_conditions_large_batch(amd, dew):
     assert torch.all(rv.sum(dim=1)[ok] < rl.sum(dim=1)[ok])
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 1000])
+def test_ragged_sizes_are_consistent(amd, n):
+    """The work queue hands rows to lanes in a run-dependent order; the results of a row must not depend on it
+    nor on the batch size."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import mix_batch
+
+    P, K, T, X, PI = mix_batch(1000, seed=31)
+    a = [_t(v).cuda() for v in (P, K, T, X, PI)]
+    for dew in (False, True):
+        full = native.mix_bubble_dew(*a, dew)
+        part = native.mix_bubble_dew(*[v[:n].contiguous() for v in a], dew)
+        assert torch.equal(part["status"], full["status"][:n])
+        assert torch.equal(part["p"], full["p"][:n])
+        assert torch.equal(part["rho4"], full["rho4"][:n])
+        again = native.mix_bubble_dew(*a, dew)
+        assert torch.equal(again["p"], full["p"]) and torch.equal(again["status"], full["status"])
+
+
 def test_empty_and_ffi_mirror(amd, oracle):
     eos = amd.PcSaftMix(torch.zeros((0, 2, 8), dtype=f64), torch.zeros((0, 2), dtype=f64))
     p, nans = eos.bubble_point(torch.zeros(0, dtype=f64), torch.zeros(0, dtype=f64), torch.zeros(0, dtype=f64))

@@ -239,6 +239,27 @@ def test_robust_pass_on_ordinary_rows(amd, oracle):
     assert np.all(got[~st] > 0)
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_sizes_are_consistent(amd, n):
+    """Rows are independent: any prefix of a batch gives bit-identical results for its rows (bucketing inside
+    the workgroup, clamped staging of the last tile, work list), on the pressure-only and the full path."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch, pure_pressures
+
+    P, T = pure_batch(1000, seed=5)
+    pp = pure_pressures(1000, seed=6)
+    Pd, Td, pd = torch.from_numpy(P).cuda(), torch.from_numpy(T).cuda(), torch.from_numpy(pp).cuda()
+    for kw in (dict(want_rho_vl=False), dict(want_rho_vl=True), dict(want_p=False, want_rho_eq=True)):
+        full = native.pure_vle(Pd, Td, **kw)
+        part = native.pure_vle(Pd[:n].contiguous(), Td[:n].contiguous(), **kw)
+        key = "rho_eq" if kw.get("want_rho_eq") else "p_sat"
+        assert torch.equal(part["status"], full["status"][:n])
+        assert torch.equal(part[key], full[key][:n])
+    full = native.pure_liquid_density(Pd, Td, pd)
+    part = native.pure_liquid_density(Pd[:n].contiguous(), Td[:n].contiguous(), pd[:n].contiguous())
+    assert torch.equal(part["rho"], full["rho"][:n]) and torch.equal(part["status"], full["status"][:n])
+
+
 def test_empty_batch(amd):
     eos = amd.PcSaftPure(torch.zeros((0, 8), dtype=f64))
     nans, vp = eos.vapor_pressure(torch.zeros(0, dtype=f64))
