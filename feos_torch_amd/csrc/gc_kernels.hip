@@ -142,7 +142,13 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_derivatives(const double* __restr
 // function form, see mix_jacobian.hpp); k_ab and phi enter the model only through the
 // aggregates (feos_torch/gc_pcsaft.py:181-194), the host chains them (gc_pcsaft.py in this package).
 constexpr int GC_DIRS = 7;   // A00, A01, A11, B00, B01, B11, T
-constexpr int GC_CHUNK = 2;
+constexpr int GC_CHUNK = 1;  // the only dual-number direction left is T
+
+// the one dual-number evaluation site of the Jacobian kernel, not inlined (register pressure, see mix_jacobian.hpp)
+template <class G, class R>
+__device__ __attribute__((noinline)) R gc_a_tangent(const GcCoef<G>& c, const R& r0, const R& r1) {
+    return gc_a<G, R>(c, r0, r1);
+}
 
 __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* __restrict__ table, int S,
                                                          const unsigned char* __restrict__ rows,
@@ -200,47 +206,62 @@ __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* 
     double w[3];
     const bool ok = solve3(A, w);
     const double p_red = dew ? s.p() : nn.p();
-    double g[GC_DIRS];
-    constexpr int NPASS = (GC_DIRS + GC_CHUNK - 1) / GC_CHUNK;
-#pragma unroll 1
-    for (int pass = 0; pass < NPASS; pass++) {
-        const int d0 = pass * GC_CHUNK;
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+    double* g = jac + GC_DIRS * i;
+
+    // (1) the six aggregates: the dispersion term is linear in them, a_disp = F1 sum_k A_k q_k + F2 sum_k B_k q_k with
+    //     q = (r0^2, r0 r1, r1^2): d(a, da/dr0, da/dr1)/dA_k = (F1 q_k, dF1/dr0 q_k + F1 dq_k/dr0, ...) -- no dual pass
+    {
+        typedef T1<double> Q;
+        Q F1s, F2s, F1i, F2i;
+        dispersion_factors(m.c, Q(s0, 1.0, 0.0), Q(s1, 0.0, 1.0), F1s, F2s);
+        dispersion_factors(m.c, Q(i0, 1.0, 0.0), Q(i1, 0.0, 1.0), F1i, F2i);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            // q_k and its gradient in both phases
+            const double qs = (k == 0) ? s0 * s0 : (k == 1 ? s0 * s1 : s1 * s1);
+            const double qs0 = (k == 0) ? 2.0 * s0 : (k == 1 ? s1 : 0.0), qs1 = (k == 0) ? 0.0 : (k == 1 ? s0 : 2.0 * s1);
+            const double qi = (k == 0) ? i0 * i0 : (k == 1 ? i0 * i1 : i1 * i1);
+            const double qi0 = (k == 0) ? 2.0 * i0 : (k == 1 ? i1 : 0.0), qi1 = (k == 0) ? 0.0 : (k == 1 ? i0 : 2.0 * i1);
+#pragma unroll
+            for (int ab = 0; ab < 2; ab++) {
+                const Q& Fs = ab == 0 ? F1s : F2s;
+                const Q& Fi = ab == 0 ? F1i : F2i;
+                const double aS = Fs.v * qs, gS0 = Fs.g0 * qs + Fs.v * qs0, gS1 = Fs.g1 * qs + Fs.v * qs1;
+                const double aI = Fi.v * qi, gI0 = Fi.g0 * qi + Fi.v * qi0, gI1 = Fi.g1 * qi + Fi.v * qi1;
+                const double dF0 = gS0 - gI0, dF1 = gS1 - gI1;
+                const double dpS = -aS + s0 * gS0 + s1 * gS1;
+                const double dpI = -aI + i0 * gI0 + i1 * gI1;
+                const double dp = (dew ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
+                g[3 * ab + k] = ok ? dp * T * P_UNIT : nanv;
+            }
+        }
+    }
+
+    // (2) T: one dual-number direction, both phases through one evaluation site
+    {
         G gT;
         gT.v = T;
-#pragma unroll
-        for (int j = 0; j < GC_CHUNK; j++) gT.e[j] = (d0 + j == 6) ? 1.0 : 0.0;
+        gT.e[0] = 1.0;
         GcCoef<G> c;
         c.bond_dab = gbonds + threadIdx.x;
         c.bond_cnt = m.c.bond_cnt;  // counts are shared (written identically)
         c.stride = GJBLOCK;
         gc_coef<G>(c, row, tb, ph0, ph1, gT);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int j = 0; j < GC_CHUNK; j++) {
-                if (d0 + j == k) c.A[k].e[j] += 1.0;
-                if (d0 + j == 3 + k) c.B[k].e[j] += 1.0;
-            }
+        double av[2], ag0[2], ag1[2];
+#pragma unroll 1
+        for (int ph = 0; ph < 2; ph++) {
+            const double q0 = ph == 0 ? s0 : i0, q1 = ph == 0 ? s1 : i1;
+            R a = gc_a_tangent<G, R>(c, R(G(q0), G(1.0), G(0.0)), R(G(q1), G(0.0), G(1.0)));
+            if (ph == 0) { av[0] = a.v.e[0]; ag0[0] = a.g0.e[0]; ag1[0] = a.g1.e[0]; }
+            else { av[1] = a.v.e[0]; ag0[1] = a.g0.e[0]; ag1[1] = a.g1.e[0]; }
         }
-        R aS = gc_a<G, R>(c, R(G(s0), G(1.0), G(0.0)), R(G(s1), G(0.0), G(1.0)));
-        R aI = gc_a<G, R>(c, R(G(i0), G(1.0), G(0.0)), R(G(i1), G(0.0), G(1.0)));
-#pragma unroll
-        for (int j = 0; j < GC_CHUNK; j++) {
-            double dF0 = aS.g0.e[j] - aI.g0.e[j];
-            double dF1 = aS.g1.e[j] - aI.g1.e[j];
-            double dpS = -aS.v.e[j] + s0 * aS.g0.e[j] + s1 * aS.g1.e[j];
-            double dpI = -aI.v.e[j] + i0 * aI.g0.e[j] + i1 * aI.g1.e[j];
-            double dp = (dew ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
-            double val = dp * T * P_UNIT;
-            if (d0 + j == 6) val += p_red * P_UNIT;
-            if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
-#pragma unroll
-            for (int d = 0; d < GC_DIRS; d++)
-                if (d == d0 + j) g[d] = val;
-        }
+        const double dF0 = ag0[0] - ag0[1], dF1 = ag1[0] - ag1[1];
+        const double dpS = -av[0] + s0 * ag0[0] + s1 * ag1[0];
+        const double dpI = -av[1] + i0 * ag0[1] + i1 * ag1[1];
+        const double dp = (dew ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
+        g[6] = ok ? dp * T * P_UNIT + p_red * P_UNIT : nanv;
     }
-#pragma unroll
-    for (int k = 0; k < GC_DIRS; k++) jac[GC_DIRS * i + k] = g[k];
 }
 
 size_t gc_lds_bytes(int S, int block, int per_thread_doubles) {

@@ -252,6 +252,29 @@ PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
     return a;
 }
 
+// The dispersion term is linear in the aggregates: a_disp = F1 (r00 A0 + r01 A1 + r11 A2) + F2 (r00 B0 + r01 B1 + r11 B2)
+// with F1 = -2 pi I1, F2 = -pi m_bar C1 I2 (same expressions as in core_terms).  Used by the gc Jacobian kernel
+// for d/dA_k, d/dB_k without a dual-number pass.
+template <class C, class R>
+PCS_DEV void dispersion_factors(const C& c, const R& r0, const R& r1, R& F1, R& F2) {
+    R zeta3 = r0 * c.zk[3][0] + r1 * c.zk[3][1];
+    R z3m1 = d_recip(1.0 - zeta3);
+    R z3m2 = z3m1 * z3m1;
+    R rs = r0 + r1;
+    R mbar = (r0 * c.m[0] + r1 * c.m[1]) * d_recip(rs);
+    R rmb = d_recip(mbar);
+    R m1 = (mbar - 1.0) * rmb;
+    R m2 = m1 * ((mbar - 2.0) * rmb);
+    R I1 = horner<7>(A0, zeta3) + m1 * horner<7>(A1, zeta3) + m2 * horner<7>(A2, zeta3);
+    R I2 = horner<7>(B0, zeta3) + m1 * horner<7>(B1, zeta3) + m2 * horner<7>(B2, zeta3);
+    R z3m4 = z3m2 * z3m2;
+    R t2 = z3m1 * d_recip(2.0 - zeta3);
+    R poly = zeta3 * (20.0 + zeta3 * (-27.0 + zeta3 * (12.0 - 2.0 * zeta3)));
+    R C1 = d_recip(1.0 + mbar * ((zeta3 * (8.0 - 2.0 * zeta3)) * z3m4) + (1.0 - mbar) * (poly * (t2 * t2)));
+    F1 = (-2.0 * PI) * I1;
+    F2 = (-PI) * ((C1 * I2) * mbar);
+}
+
 // stage 2: a(rho_0, rho_1) at fixed coefficients
 template <class P, class R>
 PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
