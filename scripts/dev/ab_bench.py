@@ -1,0 +1,43 @@
+"""A/B several builds of libpcsaft_hip (scratch/ab/lib_<name>.so) in ONE process, interleaved rounds."""
+import ctypes, sys, glob, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); os.chdir(ROOT)
+import numpy as np, torch
+from feos_torch_amd.synthetic import pure_batch
+from oracle import pyoracle as orc
+names = sys.argv[1:] or sorted(os.path.basename(f)[4:-3] for f in glob.glob("scratch/ab/lib_*.so"))
+n = 10_000_000
+P, T = pure_batch(n)
+Pd, Td = torch.from_numpy(P).cuda(), torch.from_numpy(T).cuda()
+vp = ctypes.c_void_p
+libs = {}
+for nm in names:
+    L = ctypes.CDLL(os.path.abspath(f"scratch/ab/lib_{nm}.so"))
+    L.pcs_pure_vle_fast.argtypes = [vp, vp, ctypes.c_int64] + [vp] * 7
+    L.pcs_pure_vle_retry.argtypes = [vp, vp, ctypes.c_int64] + [vp] * 7
+    libs[nm] = L
+p = torch.empty(n, dtype=torch.float64, device="cuda"); st = torch.empty(n, dtype=torch.uint8, device="cuda")
+ws = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+stream = vp(torch.cuda.current_stream().cuda_stream)
+def run(L, retry=False):
+    args = (vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, None, vp(st.data_ptr()), None, vp(ws.data_ptr()), stream)
+    assert L.pcs_pure_vle_fast(*args) == 0
+    if retry: assert L.pcs_pure_vle_retry(*args) == 0
+ns = 200_000
+ref, sref = orc.pure_vapor_pressure(P[:ns], T[:ns], prec=1)
+times = {nm: [] for nm in names}; rtimes = {nm: [] for nm in names}
+for nm in names:
+    run(libs[nm], True); torch.cuda.synchronize()
+    got = p[:ns].cpu().numpy(); sg = st[:ns].cpu().numpy().astype(bool)
+    ok = ~sg & ~sref
+    print(f"{nm:10s} max rel err vs long-double oracle {np.max(np.abs(got[ok]/ref[ok]-1)):.2e}  fails {sg.sum()} (oracle {sref.sum()}) retry rows {int(ws[0].item())}")
+for rnd in range(12):
+    for nm in names:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e2 = torch.cuda.Event(enable_timing=True)
+        e0.record(); run(libs[nm]); e1.record()
+        args = (vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, None, vp(st.data_ptr()), None, vp(ws.data_ptr()), stream)
+        libs[nm].pcs_pure_vle_retry(*args); e2.record(); torch.cuda.synchronize()
+        if rnd >= 2: times[nm].append(e0.elapsed_time(e1)); rtimes[nm].append(e1.elapsed_time(e2))
+base = np.median(times[names[0]])
+for nm in names:
+    t = np.array(times[nm]); print(f"{nm:10s} k_pure_vle median {np.median(t):.3f} ms  min {t.min():.3f}  -> {n/np.median(t)/1e6*1e3/1e3:.3f} Gsolves/s   x{base/np.median(t):.3f}   retry pass median {np.median(rtimes[nm]):.3f} ms")
