@@ -1,9 +1,9 @@
-"""A/B several builds of libpcsaft_hip (scratch/ab/lib_<name>.so) in ONE process, interleaved rounds."""
+"""A/B several builds of libpcsaft_hip (scratch/ab/lib_<name>.so) in ONE process, interleaved rounds.
+Timing only: accuracy is the business of tests/ (the oracle is not imported outside tests/, smoke() and bench.py)."""
 import ctypes, sys, glob, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); os.chdir(ROOT)
 import numpy as np, torch
 from feos_torch_amd.synthetic import pure_batch
-from oracle import pyoracle as orc
 names = sys.argv[1:] or sorted(os.path.basename(f)[4:-3] for f in glob.glob("scratch/ab/lib_*.so"))
 n = 10_000_000
 P, T = pure_batch(n)
@@ -22,14 +22,10 @@ def run(L, retry=False):
     args = (vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, None, vp(st.data_ptr()), None, vp(ws.data_ptr()), stream)
     assert L.pcs_pure_vle_fast(*args) == 0
     if retry: assert L.pcs_pure_vle_retry(*args) == 0
-ns = 200_000
-ref, sref = orc.pure_vapor_pressure(P[:ns], T[:ns], prec=1)
 times = {nm: [] for nm in names}; rtimes = {nm: [] for nm in names}
 for nm in names:
     run(libs[nm], True); torch.cuda.synchronize()
-    got = p[:ns].cpu().numpy(); sg = st[:ns].cpu().numpy().astype(bool)
-    ok = ~sg & ~sref
-    print(f"{nm:10s} max rel err vs long-double oracle {np.max(np.abs(got[ok]/ref[ok]-1)):.2e}  fails {sg.sum()} (oracle {sref.sum()}) retry rows {int(ws[0].item())}")
+    print(f"{nm:10s} fails {int(st.sum())} list entries {int(ws[0].item())}")
 for rnd in range(12):
     for nm in names:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
