@@ -50,6 +50,7 @@ PCS_DEV Eval pure_eval_mu(const PureCoef<double>& c, double rho, double& mu_res)
 #define PCS_LITE_FINISH 1
 #endif
 constexpr int LIQ_MAX_IT = 40;
+constexpr int LITE_MAX_IT = 3;
 constexpr int VLE_MAX_IT = 40;
 constexpr double ETA_START = 0.5;
 constexpr double TOL_STEP = 1e-6;  // relative Newton step at which a lane is converged (see vle_step)
@@ -283,7 +284,9 @@ PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double to
     Eval le, ve;
     le.dp = (double)dpl32;
     ve.dp = (double)dpv32;
-    for (int it = 0; it < VLE_MAX_IT; it++) {
+    // at most LITE_MAX_IT iterations: with the fp32 dp/drho the iteration converges linearly, fast (ratio ~1e-3) on
+    // ordinary rows but slowly close to the critical point where dp/drho -> 0 -- those rows go to the all-fp64 path
+    for (int it = 0; it < LITE_MAX_IT; it++) {
         if (active && !done) {
             D1s al = pure_a<double, D1s>(c, D1s(rl, 1.0));
             D1s av = pure_a<double, D1s>(c, D1s(rv, 1.0));
@@ -310,7 +313,7 @@ PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double to
 #ifdef PCS_DIAG_ITERS
     out.iters |= diag << 8;
 #endif
-    if (!warm) return ST_FALLBACK;
+    if (!warm || (active && !done)) return ST_FALLBACK;
     if (done && out.rho_v < 0.7 * out.rho_l && vapour_is_physical(out.p_star, out.rho_v)) return ST_OK;
     return ST_RETRY;
 }
