@@ -301,6 +301,32 @@ def test_wide_temperature_range_and_bad_inputs(amd, oracle):
         assert s_[plain & (tau[valid] > 1.1)].all()  # super-critical: no phase equilibrium
 
 
+def test_liquid_densities_wide_range(amd, oracle):
+    """liquid_density at 1e4..1e8 Pa and equilibrium_liquid_density from tau = 0.45 to super-critical temperatures."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch
+
+    n = 100_000
+    P, T = pure_batch(n, seed=321)
+    rng = np.random.default_rng(19)
+    tau = rng.uniform(0.45, 1.2, n)
+    T = P[:, 2] * 1.28 * P[:, 0] ** 0.45 * tau
+    pp = 1e4 * 10.0 ** rng.uniform(0, 4, n)
+    Pd, Td = torch.from_numpy(P).cuda(), torch.from_numpy(T).cuda()
+    want, sw = oracle.pure_liquid_density(P, T, pp, prec=1)
+    r = native.pure_liquid_density(Pd, Td, torch.from_numpy(pp).cuda())
+    got, st = r["rho"].cpu().numpy(), r["status"].cpu().numpy()
+    both = ~st & ~sw
+    assert both.mean() > 0.85 and np.max(np.abs(got[both] / want[both] - 1)) < 1e-9
+    assert (st & ~sw).mean() < 1e-3  # the GPU path finds every liquid root the oracle finds (and more: warm start)
+    want, sw = oracle.pure_equilibrium_liquid_density(P, T, prec=1)
+    r = native.pure_vle(Pd, Td, want_p=False, want_rho_eq=True)
+    got, st = r["rho_eq"].cpu().numpy(), r["status"].cpu().numpy()
+    both = ~st & ~sw
+    assert both.mean() > 0.7 and np.max(np.abs(got[both] / want[both] - 1)) < 1e-9
+    assert (st != sw)[tau < 0.95].mean() < 2e-3
+
+
 def test_empty_batch(amd):
     eos = amd.PcSaftPure(torch.zeros((0, 8), dtype=f64))
     nans, vp = eos.vapor_pressure(torch.zeros(0, dtype=f64))
