@@ -13,6 +13,12 @@
 
 namespace pcs {
 
+#ifndef PCS_F32_TAYLOR_MAX
+#define PCS_F32_TAYLOR_MAX 1e-3f
+#endif
+#ifndef PCS_F32_LIQ_TAYLOR
+#define PCS_F32_LIQ_TAYLOR 1
+#endif
 #ifndef PCS_F32_VIRIAL
 #define PCS_F32_VIRIAL 1
 #endif
@@ -279,7 +285,7 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
     ok = ok && done && finitef(rv) && (l.dp > 0.0f) && (rv < 0.5f * rl) && (rv > 1e-30f);
     // coupled Newton towards the equal-area pressure, to the fp32 noise floor
     done = !ok;
-    float dpv_last = 1.0f;
+    float dpv_last = 1.0f, dl_taken = 0.0f;
 #if PCS_F32_PREDICT_STOP
     float sl_prev = 1.0f, sv_prev = 1.0f;
 #endif
@@ -310,11 +316,25 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
 #else
                 done = (fabsf(dl) <= 2e-6f * rl) && (fabsf(dv) <= 3e-5f * rv);
 #endif
+                dl_taken = rln - rl;
                 rl = rln;
                 rv = rvn;
             }
         }
         if (__ballot(!done) == 0ull) break;
+#if PCS_F32_LIQ_TAYLOR
+        // the liquid barely moves after the first iteration: when no lane of the wave took a liquid step above 1e-3
+        // its state is carried to the new density by the Taylor expansion (a to 2nd, p to 1st order, dp kept) instead
+        // of a re-evaluation; the error (~2.5 (dl/rho)^2 in the density) is below the fp32 noise the pass stops at
+        if (__ballot(!done && !(fabsf(dl_taken) <= PCS_F32_TAYLOR_MAX * rl)) == 0ull) {
+            if (!done) {
+                const float a2 = (l.dp - 1.0f) * __builtin_amdgcn_rcpf(rl - dl_taken);  // a'' at the expansion point
+                l.a = fmaf(dl_taken, fmaf(0.5f * a2, dl_taken, l.mu), l.a);
+                l.mu = fmaf(a2, dl_taken, l.mu);
+                l.p = fmaf(l.dp, dl_taken, l.p);
+            }
+        } else
+#endif
         if (!done) l = pure_eval_f32(f, rl);
     }
     rl_out = (double)rl;
