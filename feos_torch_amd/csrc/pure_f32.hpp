@@ -323,19 +323,26 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
         }
         if (__ballot(!done) == 0ull) break;
 #if PCS_F32_LIQ_TAYLOR
-        // the liquid barely moves after the first iteration: when no lane of the wave took a liquid step above 1e-3
-        // its state is carried to the new density by the Taylor expansion (a to 2nd, p to 1st order, dp kept) instead
-        // of a re-evaluation; the error (~2.5 (dl/rho)^2 in the density) is below the fp32 noise the pass stops at
-        if (__ballot(!done && !(fabsf(dl_taken) <= PCS_F32_TAYLOR_MAX * rl)) == 0ull) {
-            if (!done) {
+        // the liquid barely moves after the first iteration: a lane whose liquid step was below 1e-3 carries its
+        // liquid state to the new density by the Taylor expansion (a to 2nd, p to 1st order, dp kept) instead of a
+        // re-evaluation; the error (~2.5 (dl/rho)^2 in the density) is below the fp32 noise the pass stops at.  The
+        // choice is per lane (a row's result does not depend on its wave-mates); the evaluation is skipped when no
+        // lane of the wave needs it.
+        {
+            const bool reeval = !done && !(fabsf(dl_taken) <= PCS_F32_TAYLOR_MAX * rl);
+            if (!done && !reeval) {
                 const float a2 = (l.dp - 1.0f) * __builtin_amdgcn_rcpf(rl - dl_taken);  // a'' at the expansion point
                 l.a = fmaf(dl_taken, fmaf(0.5f * a2, dl_taken, l.mu), l.a);
                 l.mu = fmaf(a2, dl_taken, l.mu);
                 l.p = fmaf(l.dp, dl_taken, l.p);
             }
-        } else
-#endif
+            if (__ballot(reeval) != 0ull) {
+                if (reeval) l = pure_eval_f32(f, rl);
+            }
+        }
+#else
         if (!done) l = pure_eval_f32(f, rl);
+#endif
     }
     rl_out = (double)rl;
     rv_out = (double)rv;
