@@ -110,7 +110,7 @@ __device__ __forceinline__ void mix_store(int64_t i, int rc, const MixResult& r,
 // K5 fast pass: small iteration caps; rows that hit a cap go to the retry list (retry[0] = count).
 // retry == nullptr: single pass with the full caps.
 #ifndef MIX_WAVES
-#define MIX_WAVES 2  // min waves per SIMD (A/B: 1..4 within 10 %, 2 fastest)
+#define MIX_WAVES 1  // the non-inlined evaluation needs the whole register file
 #endif
 template <bool DEW>
 __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const double* __restrict__ params,
