@@ -100,6 +100,40 @@ template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator-(const D2<T>& a, const 
 template <class T, PCS_IFDUAL(T)> PCS_DEV D2<T> operator-(const T& b, const D2<T>& a) { return D2<T>(b - a.v, -a.d1, -a.d2); }
 
 // =========================================================================================
+// D1<T>: value + first derivative along one direction over a component type T (the Jacobian kernels use
+// D1<DN<double,C>>: a and da/drho with their parameter tangents)
+// =========================================================================================
+template <class T>
+struct D1 {
+    T v, d1;
+    PCS_DEV D1() {}
+    PCS_DEV D1(double x) : v(x), d1(0.0) {}
+    PCS_DEV D1(const T& a, const T& b) : v(a), d1(b) {}
+    PCS_DEV D1 chain(const T& f0, const T& f1) const { return D1(f0, f1 * d1); }
+};
+template <class T> struct is_dual<D1<T>> { static constexpr bool value = true; };
+template <class T> PCS_DEV double re(const D1<T>& a) { return re(a.v); }
+template <class T> PCS_DEV D1<T> operator+(const D1<T>& a, const D1<T>& b) { return D1<T>(a.v + b.v, a.d1 + b.d1); }
+template <class T> PCS_DEV D1<T> operator-(const D1<T>& a, const D1<T>& b) { return D1<T>(a.v - b.v, a.d1 - b.d1); }
+template <class T> PCS_DEV D1<T> operator-(const D1<T>& a) { return D1<T>(-a.v, -a.d1); }
+template <class T> PCS_DEV D1<T> operator*(const D1<T>& a, const D1<T>& b) { return D1<T>(a.v * b.v, a.d1 * b.v + a.v * b.d1); }
+template <class T> PCS_DEV D1<T> operator+(const D1<T>& a, double b) { return D1<T>(a.v + b, a.d1); }
+template <class T> PCS_DEV D1<T> operator+(double b, const D1<T>& a) { return D1<T>(a.v + b, a.d1); }
+template <class T> PCS_DEV D1<T> operator-(const D1<T>& a, double b) { return D1<T>(a.v - b, a.d1); }
+template <class T> PCS_DEV D1<T> operator-(double b, const D1<T>& a) { return D1<T>(b - a.v, -a.d1); }
+template <class T> PCS_DEV D1<T> operator*(const D1<T>& a, double b) { return D1<T>(a.v * b, a.d1 * b); }
+template <class T> PCS_DEV D1<T> operator*(double b, const D1<T>& a) { return D1<T>(a.v * b, a.d1 * b); }
+template <class T> PCS_DEV D1<T> d_recip(const D1<T>& a) { T r = d_recip(a.v); return a.chain(r, -(r * r)); }
+template <class T> PCS_DEV D1<T> d_log(const D1<T>& a) { return a.chain(d_log(a.v), d_recip(a.v)); }
+template <class T> PCS_DEV D1<T> d_sqrt(const D1<T>& a) { T sq = d_sqrt(a.v); return a.chain(sq, 0.5 * d_recip(sq)); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator*(const D1<T>& a, const T& b) { return D1<T>(a.v * b, a.d1 * b); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator*(const T& b, const D1<T>& a) { return D1<T>(a.v * b, a.d1 * b); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator+(const D1<T>& a, const T& b) { return D1<T>(a.v + b, a.d1); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator+(const T& b, const D1<T>& a) { return D1<T>(a.v + b, a.d1); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator-(const D1<T>& a, const T& b) { return D1<T>(a.v - b, a.d1); }
+template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator-(const T& b, const D1<T>& a) { return D1<T>(b - a.v, -a.d1); }
+
+// =========================================================================================
 // D1s: value + first derivative along one direction, plain doubles (the solver's fp64 finish, which takes the
 // second derivative from the fp32 pre-solve).  Uses the same d_recip(double) as D2<double>.
 // =========================================================================================

@@ -22,8 +22,14 @@ constexpr int JAC_CHUNK = PCS_JAC_CHUNK;  // directions per pass
 template <int WHICH>
 PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv, double rl, double g[JAC_DIRS]) {
     typedef DN<double, JAC_CHUNK> G;
-    typedef D2<G> R;
     constexpr int NPASS = (JAC_DIRS + JAC_CHUNK - 1) / JAC_CHUNK;
+    double dp_plain = 1.0;
+    if (WHICH != 0) {
+        PureCoef<double> c0;
+        pure_coef<double>(c0, par, T, true);
+        D2<double> a0 = pure_a<double, D2<double>>(c0, D2<double>(rl, 1.0, 0.0));
+        dp_plain = 1.0 + rl * a0.d2;
+    }
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; pass++) {
         const int d0 = pass * JAC_CHUNK;
@@ -52,22 +58,25 @@ PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv
             G num = a_v * inv_v - a_l * inv_l + log(rv * inv_l);
             val = (num * (-1.0 / (inv_v - inv_l))) * gT * P_UNIT;
         } else if (WHICH == 1) {
-            // rho - (p(rho) - p_spec)/dp  (:196-199)
-            R r = pure_a<G, R>(c, R(G(rl), G(1.0), G(0.0)));
+            // rho - (p(rho) - p_spec)/dp  (:196-199).  At the root p = p_spec, so the tangent of the quotient is
+            // -(dp_tan - dp_spec_tan)/dp up to a term proportional to the last Newton step (~1e-12 relative): only a
+            // and a' need parameter tangents (D1<G>); dp/drho is a plain number from a D2<double> evaluation.
+            typedef D1<G> R1;
+            R1 r = pure_a<G, R1>(c, R1(G(rl), G(1.0)));
             G p = rl - r.v + rl * r.d1;
-            G dp = 1.0 + rl * r.d2;
             G p_spec = gP / gT * (1.0 / P_UNIT);
-            val = (rl - (p - p_spec) / dp) * (1.0 / RHO_UNIT);
+            val = (rl - (p - p_spec) * (1.0 / dp_plain)) * (1.0 / RHO_UNIT);
         } else {
-            // (:228-233)
-            R r = pure_a<G, R>(c, R(G(rl), G(1.0), G(0.0)));
+            // (:228-233), same argument: the equal-area pressure pp needs the values of a in both phases, the liquid
+            // pressure a and a'
+            typedef D1<G> R1;
+            R1 r = pure_a<G, R1>(c, R1(G(rl), G(1.0)));
             G p_l = rl - r.v + rl * r.d1;
-            G dp_l = 1.0 + rl * r.d2;
             double inv_v = 1.0 / rv, inv_l = 1.0 / rl;
             G a_l = r.v * inv_l;
             G a_v = pure_a<G, G>(c, G(rv)) * inv_v;
             G pp = (a_v - a_l + log(rv * inv_l)) * (-1.0 / (inv_v - inv_l));
-            val = (rl - (p_l - pp) / dp_l) * (1.0 / RHO_UNIT);
+            val = (rl - (p_l - pp) * (1.0 / dp_plain)) * (1.0 / RHO_UNIT);
         }
 #pragma unroll
         for (int d = 0; d < JAC_DIRS; d++) {
