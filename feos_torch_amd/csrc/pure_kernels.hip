@@ -139,9 +139,10 @@ __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __re
     int st;  // wave-uniform calls
 #if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
     if (LITE) st = vle_fast_lite(par, T, res);
-    else
+    else st = rho_eq ? vle_fast<true>(par, T, res, 1e-8, TOL_STEP) : vle_fast<true>(par, T, res);
+#else
+    st = rho_eq ? vle_fast<false>(par, T, res, 1e-8, TOL_STEP) : vle_fast<false>(par, T, res);
 #endif
-        st = rho_eq ? vle_fast(par, T, res, 1e-8, TOL_STEP) : vle_fast(par, T, res);
 
 #ifdef PCS_FORCE_RETRY  // test builds: send every row through the robust pass
     st = ST_RETRY;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __re
 // bit (the robust pass skips them), rows that need the robust pass get it cleared.
 constexpr int FALLBACK_GRID = 1024;
 __global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restrict__ params, const double* __restrict__ temp,
-                                                          double* __restrict__ p_sat, double* __restrict__ rho_vl,
+                                                          double* __restrict__ p_sat, double* __restrict__ rho_eq,
+                                                          double* __restrict__ rho_vl,
                                                           uint8_t* __restrict__ status, int32_t* __restrict__ iters,
                                                           int32_t* __restrict__ retry) {
     const int count = retry[0];
@@ -180,9 +182,10 @@ __global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restri
         for (int j = 0; j < 8; j++) par[j] = params[8 * i + j];
         const double T = temp[i];
         VleResult res;
-        int st = vle_fast(par, T, res);
+        int st = rho_eq ? vle_fast<false>(par, T, res, 1e-8, TOL_STEP) : vle_fast<false>(par, T, res);
         if (st == ST_OK) {
             if (p_sat) p_sat[i] = res.p_star * T * P_UNIT;
+            if (rho_eq) rho_eq[i] = res.rho_l * (1.0 / RHO_UNIT);
             if (rho_vl) {
                 rho_vl[2 * i] = res.rho_v;
                 rho_vl[2 * i + 1] = res.rho_l;
@@ -298,17 +301,20 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
     if (e != hipSuccess) return fail("hipMemsetAsync", e);
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
 #if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
+    // main kernel (lean: rows without an fp32 pre-solve go to the list with bit 31 set) + all-fp64 fallback kernel.
     // LITE only for the pressure-only call: its densities are converged to ~1e-9 (enough for p*, whose error is of
-    // second order in them), while the Jacobian kernels want the ~1e-12 of the full path in rho_vl
-    if (!rho_eq && !rho_vl) {
+    // second order in them), while rho_eq and the Jacobian kernels (rho_vl) want the ~1e-12 of the D2 finish.
+    if (!rho_eq && !rho_vl)
         hipLaunchKernelGGL(k_pure_vle<true>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                            iters, retry);
-        hipLaunchKernelGGL(k_pure_vle_fallback, dim3(FALLBACK_GRID), dim3(64), 0, s, params, temp, p_sat, rho_vl, status,
+    else
+        hipLaunchKernelGGL(k_pure_vle<false>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                            iters, retry);
-        e = hipGetLastError();
-        if (e != hipSuccess) return fail("k_pure_vle launch", e);
-        return 0;
-    }
+    hipLaunchKernelGGL(k_pure_vle_fallback, dim3(FALLBACK_GRID), dim3(64), 0, s, params, temp, p_sat, rho_eq, rho_vl, status,
+                       iters, retry);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_vle launch", e);
+    return 0;
 #endif
     hipLaunchKernelGGL(k_pure_vle<false>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                        iters, retry);

@@ -174,6 +174,9 @@ PCS_DEV VleStep vle_step(const Eval& l, const Eval& v, double rl, double rv) {
 // tol_l: relative liquid step at which a lane stops.  TOL_STEP suffices for the pressure (second-order
 // corrected); the saturated liquid density itself is only as good as the last step squared, so the
 // caller passes a tighter value when that output is requested.
+// LEAN: lanes without a usable fp32 pre-solve are not solved here (ST_FALLBACK, see vle_fast_lite): the main
+// kernels instantiate this, k_pure_vle_fallback the complete form.
+template <bool LEAN>
 PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
     double rl = 0.0, rv = 0.0;
     Eval l;
@@ -206,7 +209,7 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
     }
 #endif
     bool active = warm;
-    if (__ballot(!warm) != 0ull) {
+    if (!LEAN && __ballot(!warm) != 0ull) {
         // lanes without a usable fp32 result: fp64 zero-pressure liquid (the others idle through it)
         double rl0;
         int st = liquid_newton(c, 0.0, 1e-3, rl0, l, warm);
@@ -215,6 +218,7 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
             active = (st == ST_OK);
         }
     }
+    if (LEAN && !warm) { rl = 0.4 / c.ceta; rv = 1e-3 * rl; }  // harmless evaluation point for the idle lanes
     {
         double mu;
         l = pure_eval_mu(c, rl, mu);  // all lanes (wave-uniform call); also the first liquid evaluation
@@ -255,6 +259,7 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
 #if defined(PCS_DIAG_ITERS) && defined(PCS_F32_PRESOLVE)
     out.iters |= diag << 8;
 #endif
+    if (LEAN && !warm) return ST_FALLBACK;
     if (done && out.rho_v < 0.7 * out.rho_l && vapour_is_physical(out.p_star, out.rho_v)) return ST_OK;
     return ST_RETRY;  // includes cap hit and near-critical states: let the robust path decide
 }
