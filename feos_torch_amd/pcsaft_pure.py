@@ -41,13 +41,21 @@ class _PureProperty(torch.autograd.Function):
             value = r["p_sat"] if which == "vapor_pressure" else r["rho_eq"]
             rho_vl = r["rho_vl"]
         nans = r["status"]
-        ok = ~nans
-        value = value[ok]
+        # every row converged (the common case): no compaction, no gathers
+        all_ok = not bool(nans.any())
+        ok = None if all_ok else ~nans
+        if not all_ok:
+            value = value[ok]
         needs = list(ctx.needs_input_grad[1:4])
         if any(needs):
             # Jacobian only on converged rows (dense kernel on the compacted inputs)
-            jac = native.pure_jacobian(which, par[ok], T[ok], None if P is None else P[ok], rho_vl[ok])
-            ctx.save_for_backward(jac, ok)
+            if all_ok:
+                jac = native.pure_jacobian(which, par, T, P, rho_vl)
+                ctx.save_for_backward(jac)
+            else:
+                jac = native.pure_jacobian(which, par[ok], T[ok], None if P is None else P[ok], rho_vl[ok])
+                ctx.save_for_backward(jac, ok)
+        ctx.all_ok = all_ok
         ctx.needs = needs
         ctx.n = T.shape[0]
         ctx.out_device = out_device
@@ -58,22 +66,28 @@ class _PureProperty(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_value, _g_nans):
-        jac, ok = ctx.saved_tensors
+        if ctx.all_ok:
+            (jac,) = ctx.saved_tensors
+            ok = None
+        else:
+            jac, ok = ctx.saved_tensors
         g = g_value.to(jac.device)
         n = ctx.n
+
+        def scatter(x, tail):
+            if ok is None:
+                return x
+            out = torch.zeros((n,) + tail, dtype=torch.float64, device=jac.device)
+            out[ok] = x
+            return out
+
         gp = gt = gpr = None
         if ctx.needs[0]:
-            gp = torch.zeros((n, 8), dtype=torch.float64, device=jac.device)
-            gp[ok] = g[:, None] * jac[:, 0:8]
-            gp = gp.to(ctx.in_devices[0])
+            gp = scatter(g[:, None] * jac[:, 0:8], (8,)).to(ctx.in_devices[0])
         if ctx.needs[1]:
-            gt = torch.zeros(n, dtype=torch.float64, device=jac.device)
-            gt[ok] = g * jac[:, 8]
-            gt = gt.to(ctx.in_devices[1])
+            gt = scatter(g * jac[:, 8], ()).to(ctx.in_devices[1])
         if ctx.needs[2]:
-            gpr = torch.zeros(n, dtype=torch.float64, device=jac.device)
-            gpr[ok] = g * jac[:, 9]
-            gpr = gpr.to(ctx.in_devices[2])
+            gpr = scatter(g * jac[:, 9], ()).to(ctx.in_devices[2])
         return None, gp, gt, gpr
 
 
@@ -134,4 +148,5 @@ class PcSaftPure:
 
     def reduce(self, nans):
         """Drop the rows flagged in ``nans`` from the model (:235-243)."""
-        self._set(self._par[~nans.to(self._par.device)])
+        if bool(nans.any()):
+            self._set(self._par[~nans.to(self._par.device)])
