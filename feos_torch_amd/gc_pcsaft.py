@@ -103,13 +103,15 @@ class _GcBubbleDew(torch.autograd.Function):
         r = native.gc_bubble_dew(table, model.S, model.rows, ph, T, native._prep(molefracs, dev),
                                  native._prep(pressure, dev), dew)
         nans = r["status"]
-        ok = ~nans
+        all_ok = not bool(nans.any())  # every row converged: slices instead of boolean gathers
+        ok = slice(None) if all_ok else ~nans
         value = r["p"][ok]
         needs = [ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]]
         if any(needs):
             rows_ok = model.rows[ok]
             jac, agg = native.gc_jacobian(table, model.S, rows_ok, ph[ok], T[ok], r["rho4"][ok], dew)
-            ctx.save_for_backward(jac, agg, ok, rows_ok, ph[ok], T[ok], table)
+            ctx.save_for_backward(jac, agg, nans.new_empty(0) if all_ok else ok, rows_ok, ph[ok], T[ok], table)
+        ctx.all_ok = all_ok
         ctx.needs = needs
         ctx.S = model.S
         ctx.n = T.shape[0]
@@ -122,6 +124,8 @@ class _GcBubbleDew(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_value, _g):
         jac, agg, ok, rows, ph, T, table = ctx.saved_tensors
+        if ctx.all_ok:
+            ok = slice(None)
         S, n = ctx.S, ctx.n
         g = g_value.to(jac.device)
         gk = gphi = gT = None
@@ -215,6 +219,8 @@ class GcPcSaftMix:
 
     def reduce(self, nans):
         """Drop failed rows from the model (:514-528)."""
+        if not bool(nans.any()):
+            return
         self.rows = self.rows[~nans.to(self.rows.device)]
         self.phi = self.phi[~nans.to(self.phi.device)]
 

@@ -26,12 +26,18 @@ class _BubbleDew(torch.autograd.Function):
         p0 = native._prep(pressure, dev)
         r = native.mix_bubble_dew(par, k, T, z, p0, dew)
         nans = r["status"]
-        ok = ~nans
-        value = r["p"][ok]
+        all_ok = not bool(nans.any())  # every row converged: no compaction, no gathers
+        ok = None if all_ok else ~nans
+        value = r["p"] if all_ok else r["p"][ok]
         needs = list(ctx.needs_input_grad[1:4])
         if any(needs):
-            jac = native.mix_jacobian(par[ok], k[ok], T[ok], r["rho4"][ok], dew)
-            ctx.save_for_backward(jac, ok)
+            if all_ok:
+                jac = native.mix_jacobian(par, k, T, r["rho4"], dew)
+                ctx.save_for_backward(jac)
+            else:
+                jac = native.mix_jacobian(par[ok], k[ok], T[ok], r["rho4"][ok], dew)
+                ctx.save_for_backward(jac, ok)
+        ctx.all_ok = all_ok
         ctx.needs = needs
         ctx.n = T.shape[0]
         ctx.in_devices = (parameters.device, kij.device, temperature.device)
@@ -41,22 +47,28 @@ class _BubbleDew(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_value, _g_nans):
-        jac, ok = ctx.saved_tensors
+        if ctx.all_ok:
+            (jac,) = ctx.saved_tensors
+            ok = None
+        else:
+            jac, ok = ctx.saved_tensors
         g = g_value.to(jac.device)
         n = ctx.n
+
+        def scatter(x, tail):
+            if ok is None:
+                return x
+            out = torch.zeros((n,) + tail, dtype=torch.float64, device=jac.device)
+            out[ok] = x
+            return out
+
         gp = gk = gt = None
         if ctx.needs[0]:
-            gp = torch.zeros((n, 16), dtype=torch.float64, device=jac.device)
-            gp[ok] = g[:, None] * jac[:, 0:16]
-            gp = gp.view(n, 2, 8).to(ctx.in_devices[0])
+            gp = scatter(g[:, None] * jac[:, 0:16], (16,)).view(n, 2, 8).to(ctx.in_devices[0])
         if ctx.needs[1]:
-            gk = torch.zeros((n, 2), dtype=torch.float64, device=jac.device)
-            gk[ok] = g[:, None] * jac[:, 16:18]
-            gk = gk.to(ctx.in_devices[1])
+            gk = scatter(g[:, None] * jac[:, 16:18], (2,)).to(ctx.in_devices[1])
         if ctx.needs[2]:
-            gt = torch.zeros(n, dtype=torch.float64, device=jac.device)
-            gt[ok] = g * jac[:, 18]
-            gt = gt.to(ctx.in_devices[2])
+            gt = scatter(g * jac[:, 18], ()).to(ctx.in_devices[2])
         return None, gp, gk, gt, None, None
 
 
@@ -115,5 +127,7 @@ class PcSaftMix:
 
     def reduce(self, nans):
         """Drop the rows flagged in ``nans`` (:470-479)."""
+        if not bool(nans.any()):
+            return
         keep = ~nans.to(self._par.device)
         self._set(self._par[keep], self.kij[keep.to(self.kij.device)])
