@@ -37,6 +37,31 @@ def test_abi_version_and_error_string(hip_lib):
     assert hip_lib.pcs_workspace_bytes(1000) == 4 * (1000 + 64)  # row order / retry list + control block
 
 
+def test_argument_validation_without_gpu(hip_lib):
+    """Every entry point rejects bad sizes / missing required pointers before it touches the device: non-zero return,
+    message in pcs_last_error, and n = 0 is a no-op (the reference panics on invalid input, src/pcsaft.rs:89)."""
+    import ctypes
+
+    L = hip_lib
+    nul = None
+    one = ctypes.c_void_p(8)  # never dereferenced: the checks come first
+    calls = {
+        "pcs_pure_vle": lambda n, req: L.pcs_pure_vle(req, req, n, nul, nul, nul, req, nul, req, nul),
+        "pcs_pure_liquid_density": lambda n, req: L.pcs_pure_liquid_density(req, req, req, n, nul, nul, req, nul),
+        "pcs_pure_derivatives": lambda n, req: L.pcs_pure_derivatives(req, req, req, n, nul, nul, nul, nul),
+        "pcs_mix_bubble_dew": lambda n, req: L.pcs_mix_bubble_dew(0, req, req, req, req, req, n, nul, nul, req, nul, nul, nul),
+        "pcs_mix_derivatives": lambda n, req: L.pcs_mix_derivatives(req, req, req, req, n, nul, nul, nul, nul, nul),
+        "pcs_mix_jacobian": lambda n, req: L.pcs_mix_jacobian(0, req, req, req, req, n, req, nul),
+    }
+    for name, call in calls.items():
+        assert call(0, nul) == 0, name  # empty batch: nothing to check, nothing to do
+        for n, req in ((-1, one), (1 << 31, one), (5, nul)):
+            assert call(n, req) != 0, (name, n)
+            assert L.pcs_last_error() != b"", name
+    assert L.pcs_pure_jacobian(7, one, one, nul, one, 5, one, nul) != 0  # unknown property selector
+    assert b"which" in L.pcs_last_error()
+
+
 def test_product_has_no_cpu_fallback():
     import torch
 
