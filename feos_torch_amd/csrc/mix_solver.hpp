@@ -203,16 +203,20 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
             // not small (composition moved a lot) or the linearisation is unusable.
             PhaseEval e;
             double drho = 0.0;
+            bool fine_prev = false;
 #pragma unroll 1
             for (int attempt = 0; attempt < 2; attempt++) {
                 if (!have || attempt == 1) {
-                    if (!liquid_root(m, x0, x1, 0.0, rl) && !liquid_root(m, x0, x1, p0, rl)) return BD_FAILED;
+                    // a re-solve starts from the tracked density when the evaluation there was usable
+                    const double warm = (have && attempt == 1 && fine_prev) ? rl : 0.0;
+                    if (!liquid_root(m, x0, x1, 0.0, rl, warm) && !liquid_root(m, x0, x1, p0, rl)) return BD_FAILED;
                     have = true;
                 }
                 e = phase_eval(m, x0 * rl, x1 * rl);
                 double p = e.p(), dp = x0 * e.dp0() + x1 * e.dp1();
                 drho = -p / dp;
                 bool fine = (dp > 0.0) && is_finite_bits(p);
+                fine_prev = fine;
                 if (fine && fabs(drho) <= 0.05 * rl) break;
                 if (attempt == 1) {
                     if (!fine) return BD_FAILED;

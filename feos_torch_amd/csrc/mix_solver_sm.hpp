@@ -29,7 +29,7 @@ struct BdLane {
     int ss_max, newton_max;
     // liquid-root sub-machine
     int r_for, r_it;
-    bool r_dense, r_has_alt;
+    bool r_dense, r_has_alt, r_warm;
     double r_x0, r_x1, r_pk, r_rho, r_pspec, r_palt, r_errprev;
     // dew initialisation
     double f0, x0, x1, p0, rl, xi_prev, res_prev;
@@ -45,12 +45,16 @@ struct BdLane {
     PCS_DEV bool done() const { return stage == S_DONE; }
 
     template <class Model>
-    PCS_DEV void start_root(const Model& m, int who, double xa, double xb, double pspec, bool has_alt, double palt) {
+    PCS_DEV void start_root(const Model& m, int who, double xa, double xb, double pspec, bool has_alt, double palt,
+                            double rho_start = 0.0) {
         r_for = who;
         r_x0 = xa;
         r_x1 = xb;
         r_pk = m.packing(xa, xb);
-        r_rho = 0.5 / r_pk;
+        // warm start from the liquid density tracked at the previous composition (re-solves during the substitution);
+        // a warm start that misbehaves falls back to the cold one
+        r_warm = rho_start > 0.0 && rho_start * r_pk < 0.7;
+        r_rho = r_warm ? rho_start : 0.5 / r_pk;
         r_pspec = pspec;
         r_has_alt = has_alt;
         r_palt = palt;
@@ -88,9 +92,10 @@ struct BdLane {
     template <class Model>
     PCS_DEV void consume(const Model& m, const PhaseEval& e) {
 #define PCS_SM_START_ROOT(who, xa, xb, pspec, has_alt, palt) start_root(m, who, xa, xb, pspec, has_alt, palt)
+#define PCS_SM_START_ROOT_WARM(who, xa, xb, pspec, has_alt, palt, rho0) start_root(m, who, xa, xb, pspec, has_alt, palt, rho0)
         if (stage == S_ROOT) {
             double p = e.p(), dp = r_x0 * e.dp0() + r_x1 * e.dp1();
-            if (r_it == 0 && !r_dense && !(p > r_pspec)) {
+            if (r_it == 0 && !r_dense && !r_warm && !(p > r_pspec)) {
                 r_rho = 0.62 / r_pk;  // very cold / dense: restart on the dense side (plain Newton from there)
                 r_dense = true;
                 return;
@@ -107,6 +112,10 @@ struct BdLane {
                 r_errprev = err;
                 r_it++;
                 if (!done && r_it >= LIQ_ROOT_MAX_IT) bad = true;
+            }
+            if (bad && r_warm) {  // the warm start left the liquid branch: same root from the cold start
+                PCS_SM_START_ROOT(r_for, r_x0, r_x1, r_pspec, r_has_alt, r_palt);
+                return;
             }
             if (bad) {
                 if (r_has_alt) {  // second choice of the specified pressure
@@ -156,7 +165,7 @@ struct BdLane {
             if (!(fine && fabs(drho) <= 0.05 * rl)) {
                 if (!resolved) {  // composition moved a lot: re-solve the liquid root here, then redo the sweep
                     resolved = true;
-                    PCS_SM_START_ROOT(R_SS, x0, x1, 0.0, true, p0);
+                    PCS_SM_START_ROOT_WARM(R_SS, x0, x1, 0.0, true, p0, fine ? rl : 0.0);
                     return;
                 }
                 if (!fine) { stage = S_DONE; return; }
@@ -261,6 +270,7 @@ struct BdLane {
         rc = is_finite_bits(out.p) ? BD_OK : BD_FAILED;
         stage = S_DONE;
 #undef PCS_SM_START_ROOT
+#undef PCS_SM_START_ROOT_WARM
     }
 };
 

@@ -70,31 +70,35 @@ constexpr double LIQ_ROOT_TOL = 1e-6;
 constexpr int NEWTON_NO_PROGRESS = 30;
 constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point successive substitution hands over to Newton
 template <class F, class Model>
-bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out) {
+bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out, F rho_start = F(0)) {
     static const bool plain = getenv("ORC_LIQ_PLAIN") != nullptr;
     static const double tol = getenv("ORC_LIQ_TOL") ? atof(getenv("ORC_LIQ_TOL")) : LIQ_ROOT_TOL;
     F pk = model.packing(T, x);
-    F rho = F(0.5) / pk;
+    // warm start (re-solves during the dew-point substitution); a warm start that misbehaves falls back to the cold one
+    const bool warm = rho_start > F(0) && rho_start * pk < F(0.7);
+    F rho = warm ? rho_start : F(0.5) / pk;
     F err_prev = F(1);
     bool dense = false;
     for (int it = 0; it < 30; it++) {  // same cap as the kernels
         F r[2] = {x[0] * rho, x[1] * rho};
         PhaseEval<F> e = eval_phase<F>(model, T, r);
         F p = e.p(), dp = x[0] * e.dp(0) + x[1] * e.dp(1);
-        if (it == 0 && !(p > p_spec)) { rho = F(0.62) / pk; dense = true; continue; }
+        if (it == 0 && !warm && !(p > p_spec)) { rho = F(0.62) / pk; dense = true; continue; }
         if (getenv("ORC_TRACE_LIQ")) fprintf(stderr, "  liq it %d eta %.5f p %.4e dp %.4e p_spec %.3e\n", it, (double)(rho * pk), (double)p, (double)dp, (double)p_spec);
-        if (!(dp > 0) || !(p == p)) return false;
         F den = (dense || plain) ? dp : dp - F(4) * (p - p_spec) * pk / (F(1) - rho * pk);
-        if (!(den > 0)) return false;
         F step = (p - p_spec) / den;
         F rho_new = rho - step;
-        if (!(rho_new > 0)) return false;
+        if (!(dp > 0) || !(p == p) || !(den > 0) || !(rho_new > 0) || !(rho_new == rho_new)) {
+            if (warm) return liquid_root<F>(model, T, x, p_spec, rho_out);
+            return false;
+        }
         F err = (step < 0 ? -step : step) / rho;
         bool done = err <= F(tol) || (it >= 3 && err < F(1e-7) && err >= F(0.25) * err_prev);
         err_prev = err;
         rho = rho_new;
         if (done) { rho_out = rho; return true; }
     }
+    if (warm) return liquid_root<F>(model, T, x, p_spec, rho_out);
     return false;
 }
 
@@ -174,9 +178,12 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             // not small (composition moved a lot) or the linearisation is unusable.
             PhaseEval<F> e;
             F drho = F(0);
+            bool fine_prev = false;
             for (int attempt = 0; attempt < 2; attempt++) {
                 if (!have || attempt == 1) {
-                    if (!liquid_root<F>(model, T, x, F(0), rl) && !liquid_root<F>(model, T, x, p0, rl)) {
+                    // a re-solve starts from the tracked density when the evaluation there was usable
+                    const F warm_rho = (have && attempt == 1 && fine_prev) ? rl : F(0);
+                    if (!liquid_root<F>(model, T, x, F(0), rl, warm_rho) && !liquid_root<F>(model, T, x, p0, rl)) {
                         if (getenv("ORC_TRACE")) fprintf(stderr, "FAIL ss-liquid-root ss %d x %.6e %.6e p0 %.6e\n", ss, (double)x[0], (double)x[1], (double)p0);
                         return false;
                     }
@@ -187,6 +194,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
                 F p = e.p(), dp = x[0] * e.dp(0) + x[1] * e.dp(1);
                 drho = -p / dp;
                 F ad = drho < 0 ? -drho : drho;
+                fine_prev = dp > 0 && p == p;
                 if (ss_track && dp > 0 && p == p && ad <= F(0.05) * rl) break;
                 if (attempt == 1) { if (!(dp > 0) || !(p == p)) return false; if (!(ad <= F(0.05) * rl)) drho = F(0); }
             }
