@@ -244,9 +244,14 @@ PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
                 double s0, s1;
                 gc_cross_step<double>(x0, x1, e00, e01, e10, e11, s0, s1);
                 double n0 = x0 - s0, n1 = x1 - s1;
-                if (!(n0 > 0.0 && n0 <= 1.5 && n1 > 0.0 && n1 <= 1.5)) {  // successive substitution fallback
-                    n0 = 1.0 / (1.0 + x0 * e00 + x1 * e01);
-                    n1 = 1.0 / (1.0 + x0 * e10 + x1 * e11);
+                if (!(n0 > 0.0 && n0 <= 1.5 && n1 > 0.0 && n1 <= 1.5)) {
+                    if (it < 60 && is_finite_bits(s0) && is_finite_bits(s1)) {  // Newton step in ln X (see mix_model.hpp)
+                        n0 = fmin(x0 * exp(fmin(fmax(-s0 / x0, -3.0), 3.0)), 1.0);
+                        n1 = fmin(x1 * exp(fmin(fmax(-s1 / x1, -3.0), 3.0)), 1.0);
+                    } else {  // successive substitution fallback
+                        n0 = 1.0 / (1.0 + x0 * e00 + x1 * e01);
+                        n1 = 1.0 / (1.0 + x0 * e10 + x1 * e11);
+                    }
                 }
                 // 1e-12 is enough: the two Newton updates in R arithmetic below square the remaining error
                 bool conv = fabs(n0 - x0) <= 1e-12 * x0 && fabs(n1 - x1) <= 1e-12 * x1;

@@ -333,10 +333,18 @@ PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
                 cross_step<double>(x0, x1, a0, a1, b0, b1, e00, e01, e11, s0, s1);
                 double n0 = x0 - s0, n1 = x1 - s1;
                 if (!(n0 > 0.0 && n0 <= 1.5 && n1 > 0.0 && n1 <= 1.5)) {
-                    double u0 = 1.0 / (1.0 + x0 * a0 * e00 + x1 * a1 * e01);
-                    double u1 = 1.0 / (1.0 + x0 * a0 * e01 + x1 * a1 * e11);
-                    n0 = 1.0 / (1.0 + u0 * b0 * e00 + u1 * b1 * e01);
-                    n1 = 1.0 / (1.0 + u0 * b0 * e01 + u1 * b1 * e11);
+                    if (it < 60 && is_finite_bits(s0) && is_finite_bits(s1)) {
+                        // the Newton step leaves (0, 1.5]: take it in ln X instead (X <- X exp(-dX/X), at most a
+                        // factor e^3 per component, capped at 1).  Strong association puts the root at X ~ 1e-5,
+                        // which the successive substitution below approaches only sub-linearly.
+                        n0 = fmin(x0 * exp(fmin(fmax(-s0 / x0, -3.0), 3.0)), 1.0);
+                        n1 = fmin(x1 * exp(fmin(fmax(-s1 / x1, -3.0), 3.0)), 1.0);
+                    } else {
+                        double u0 = 1.0 / (1.0 + x0 * a0 * e00 + x1 * a1 * e01);
+                        double u1 = 1.0 / (1.0 + x0 * a0 * e01 + x1 * a1 * e11);
+                        n0 = 1.0 / (1.0 + u0 * b0 * e00 + u1 * b1 * e01);
+                        n1 = 1.0 / (1.0 + u0 * b0 * e01 + u1 * b1 * e11);
+                    }
                 }
                 // 1e-12 is enough: the two Newton updates in R arithmetic below square the remaining error
                 bool conv = fabs(n0 - x0) <= 1e-12 * x0 && fabs(n1 - x1) <= 1e-12 * x1;

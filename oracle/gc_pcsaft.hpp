@@ -261,8 +261,19 @@ S gc_helmholtz_energy_density(const GcRow& r, const S& T, const S* rho, const S*
                     gc_cross_step<R>(x0, x1, r00, r01, r10, r11, h0, h1, e0, e1);
                     R n0 = x0 - e0, n1 = x1 - e1;
                     if (!(n0 > 0 && n0 <= R(1.5) && n1 > 0 && n1 <= R(1.5))) {
-                        n0 = R(1) / (R(1) + x0 * r00 + x1 * r01);  // successive substitution, lands in (0, 1]
-                        n1 = R(1) / (R(1) + x0 * r10 + x1 * r11);
+                        if (it < 60 && e0 == e0 && e1 == e1) {
+                            // Newton step in ln X (see oracle/pcsaft_mix.hpp, phi_cross_assoc)
+                            R q0 = -e0 / x0, q1 = -e1 / x1;
+                            q0 = q0 > R(3) ? R(3) : (q0 < R(-3) ? R(-3) : q0);
+                            q1 = q1 > R(3) ? R(3) : (q1 < R(-3) ? R(-3) : q1);
+                            n0 = x0 * exp(q0);
+                            n1 = x1 * exp(q1);
+                            if (n0 > R(1)) n0 = R(1);
+                            if (n1 > R(1)) n1 = R(1);
+                        } else {
+                            n0 = R(1) / (R(1) + x0 * r00 + x1 * r01);  // successive substitution, lands in (0, 1]
+                            n1 = R(1) / (R(1) + x0 * r10 + x1 * r11);
+                        }
                     }
                     R c0 = (n0 - x0) / x0, c1 = (n1 - x1) / x1;
                     x0 = n0;

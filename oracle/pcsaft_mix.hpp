@@ -203,11 +203,24 @@ S phi_cross_assoc(const MixParams<S>& q, const S& T, const S* rho, const S* d, c
             cross_newton_step<R>(x0, x1, ra, rb, r00, r01, r10, r11, h0, h1, e0, e1);
             R n0 = x0 - e0, n1 = x1 - e1;
             if (!(n0 > 0 && n0 <= R(1.5) && n1 > 0 && n1 <= R(1.5))) {
+                if (it < 60 && e0 == e0 && e1 == e1) {
+                    // the Newton step leaves (0, 1.5]: take it in ln X instead (X <- X exp(-dX/X), at most a factor
+                    // e^3 per component, capped at 1).  Strong association puts the root at X ~ 1e-5, which the
+                    // successive substitution below approaches only sub-linearly.
+                    R q0 = -e0 / x0, q1 = -e1 / x1;
+                    q0 = q0 > R(3) ? R(3) : (q0 < R(-3) ? R(-3) : q0);
+                    q1 = q1 > R(3) ? R(3) : (q1 < R(-3) ? R(-3) : q1);
+                    n0 = x0 * exp(q0);
+                    n1 = x1 * exp(q1);
+                    if (n0 > R(1)) n0 = R(1);
+                    if (n1 > R(1)) n1 = R(1);
+                } else {
                 // successive substitution X_Ai = 1/(1 + sum_j X_Bj rhob_j Delta_ij): lands in (0, 1]
                 R xb0 = R(1) / (R(1) + x0 * ra[0] * r00 + x1 * ra[1] * r01);
                 R xb1 = R(1) / (R(1) + x0 * ra[0] * r10 + x1 * ra[1] * r11);
                 n0 = R(1) / (R(1) + xb0 * rb[0] * r00 + xb1 * rb[1] * r01);
                 n1 = R(1) / (R(1) + xb0 * rb[0] * r10 + xb1 * rb[1] * r11);
+                }
             }
             R c0 = (n0 - x0) / x0, c1 = (n1 - x1) / x1;
             x0 = n0;
