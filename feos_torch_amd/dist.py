@@ -108,3 +108,24 @@ def sharded_vapor_pressure(params, temperature, compute=None, group=None):
     p = gather_rows(p_loc, n, group)
     st = gather_rows(st_loc.to(torch.uint8), n, group).bool()
     return p, st
+
+
+def sharded_rows(compute, *row_tensors, group=None):
+    """Generic form: every tensor in ``row_tensors`` has the batch as its first dimension; each rank applies
+    ``compute(*shards)`` (returning a tuple of tensors with the shard's rows first) to its contiguous shard and the
+    outputs are re-assembled on every rank.  Bubble / dew points, liquid densities, Jacobians ... shard this way:
+    no row interacts with another."""
+    n = row_tensors[0].shape[0]
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_bounds(n, rank, world)
+    outs = compute(*[t[lo:hi] for t in row_tensors])
+    gathered = []
+    for o in outs:
+        as_u8 = o.dtype == torch.bool
+        g = gather_rows(o.to(torch.uint8) if as_u8 else o, n, group)
+        gathered.append(g.bool() if as_u8 else g)
+    return tuple(gathered)
+

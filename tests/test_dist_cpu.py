@@ -60,6 +60,47 @@ def test_sharded_vapor_pressure_matches_unsharded(oracle, n):
         assert np.array_equal(got, want)  # same arithmetic per row -> bit identical
 
 
+def _worker_mix(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from feos_torch_amd import dist as pdist
+    from feos_torch_amd.synthetic import mix_batch
+    from oracle import pyoracle as orc
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def compute(par, kij, T, z, p0):
+        p, rho4, st = orc.mix_bubble_dew(par.numpy(), kij.numpy(), T.numpy(), z.numpy(), p0.numpy(), False)
+        return torch.from_numpy(p), torch.from_numpy(rho4), torch.from_numpy(st)
+
+    b = [torch.from_numpy(np.ascontiguousarray(v)) for v in mix_batch(n, seed=4)]
+    p, rho4, st = pdist.sharded_rows(compute, *b)
+    q.put((rank, p.numpy(), rho4.numpy(), st.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_rows_generic_bubble_points(oracle):
+    """sharded_rows with a multi-output, multi-input row-wise solve ([n], [n,4] and bool outputs), uneven shards."""
+    from feos_torch_amd.synthetic import mix_batch
+
+    n, world = 301, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mix, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_p, want_rho, want_st = oracle.mix_bubble_dew(*mix_batch(n, seed=4), False)
+    for _, p_, rho_, st_ in results:
+        assert st_.dtype == np.bool_ and np.array_equal(st_, want_st)
+        assert np.array_equal(p_, want_p) and np.array_equal(rho_, want_rho)
+
+
 def test_shard_bounds_cover_every_row_once():
     from feos_torch_amd.dist import shard_bounds
 
