@@ -42,3 +42,11 @@ def hip_lib():
     from feos_torch_amd import _lib
 
     return _lib.lib()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _host_extension():
+    """The native gc row encoder (g++, host code) is built on demand like the oracle."""
+    from feos_torch_amd import build
+
+    build.build_host()
