@@ -171,6 +171,30 @@ def test_ragged_sizes_are_consistent(amd, n):
         assert torch.equal(again["p"], full["p"]) and torch.equal(again["status"], full["status"])
 
 
+def test_single_pass_schedule_without_workspace(amd):
+    """pcs_mix_bubble_dew with workspace = NULL (one row per lane, no work queue) solves the same rows as the queue."""
+    import ctypes
+
+    from feos_torch_amd import _lib, native
+    from feos_torch_amd.synthetic import mix_batch
+
+    n = 2000
+    a = [_t(v).cuda() for v in mix_batch(n, seed=37)]
+    L = _lib.lib()
+    for dew in (False, True):
+        ref = native.mix_bubble_dew(*a, dew)
+        p = torch.empty(n, dtype=f64, device="cuda")
+        rho4 = torch.empty((n, 4), dtype=f64, device="cuda")
+        st = torch.empty(n, dtype=torch.uint8, device="cuda")
+        rc = L.pcs_mix_bubble_dew(int(dew), *[_lib.ptr(v) for v in a], n, _lib.ptr(p), _lib.ptr(rho4), _lib.ptr(st),
+                                  None, None, _lib.current_stream_ptr(p.device))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(st.bool(), ref["status"])
+        # same solver code inlined into two different kernels: identical up to the compiler's FMA contraction
+        assert torch.allclose(p, ref["p"], rtol=1e-11, atol=0.0) and torch.allclose(rho4, ref["rho4"], rtol=1e-10, atol=0.0)
+
+
 def test_empty_and_ffi_mirror(amd, oracle):
     eos = amd.PcSaftMix(torch.zeros((0, 2, 8), dtype=f64), torch.zeros((0, 2), dtype=f64))
     p, nans = eos.bubble_point(torch.zeros(0, dtype=f64), torch.zeros(0, dtype=f64), torch.zeros(0, dtype=f64))
