@@ -8,7 +8,12 @@
 // Newton in the logarithms of the three unknowns with the full analytic Jacobian from one
 // T2<double> evaluation per phase.  Initialisation: bubble — liquid root at the caller's initial
 // pressure, ideal vapour at the liquid's fugacities; dew — Raoult's law from zero-pressure pure-
-// liquid fugacities, refined by ideal-vapour successive substitution.
+// liquid fugacities (the caller's pressure and the vapour composition where a pure-component limit
+// of the model is not finite), refined by ideal-vapour successive substitution: a scalar fixed-point
+// map in ln(x_1/x_2), iterated with secant steps, the liquid density carried along by the Newton step
+// each sweep's evaluation provides (re-solved, from the tracked density, only when that step is large).
+// This file is the sequential form (readable, restated 1:1 by oracle/mix_solver.hpp, used by the
+// single-pass kernels); mix_solver_sm.hpp is the same algorithm as a per-lane state machine.
 // The returned pressure is the reference's final explicit Newton step (feos_torch/
 // pcsaft_mix.py:435-444 / :459-468) evaluated at the converged densities.
 //
