@@ -247,7 +247,10 @@ PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
         R phi2 = r00 * horner<5>(c.pj[0], zeta3) + r01 * horner<5>(c.pj[1], zeta3) + r11 * horner<5>(c.pj[2], zeta3);
         R phi3 = (r00 * r0) * horner<4>(c.tj[0], zeta3) + (r00 * r1) * horner<4>(c.tj[1], zeta3) +
                  (r0 * r11) * horner<4>(c.tj[2], zeta3) + (r11 * r1) * horner<4>(c.tj[3], zeta3);
-        a = a + (phi2 * phi2) * d_recip(phi2 - phi3);
+        // phi2 = phi3 = 0 where no polar component is present (pure-component limit next to a polar partner): the
+        // quotient's limit is phi2 + O(rho_polar^3) (value and gradient 0, Hessian that of phi2)
+        if (re(phi2) == 0.0) a = a + phi2;
+        else a = a + (phi2 * phi2) * d_recip(phi2 - phi3);
     }
     return a;
 }

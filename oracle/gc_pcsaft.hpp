@@ -218,7 +218,9 @@ S gc_helmholtz_energy_density(const GcRow& r, const S& T, const S* rho, const S*
         }
         phi2 = phi2 * PI;
         phi3 = phi3 * (4.0 / 3.0 * PI * PI);
-        phi = phi + phi2 * phi2 / (phi2 - phi3);
+        // 0/0 where no polar component is present: limit phi2 + O(rho_polar^3) (see pcsaft_mix.hpp)
+        if (re(phi2) == 0.0) phi = phi + phi2;
+        else phi = phi + phi2 * phi2 / (phi2 - phi3);
     }
 
     // association (:221-251)

@@ -121,6 +121,10 @@ S phi_dipole(const MixParams<S>& q, const S& T, const S* rho, const S* etas) {
     }
     phi2 = phi2 * PI;
     phi3 = phi3 * (4.0 / 3.0 * PI * PI);
+    // phi2 and phi3 vanish together where no polar component is present (a pure-component limit of a
+    // mixture with one polar partner): the quotient is 0/0 in the reference's Python; its limit is
+    // phi2 + O(rho_polar^3), which is what feos' dipole term (the solver's own model) returns there.
+    if (re(phi2) == 0.0) return phi2;
     return phi2 * phi2 / (phi2 - phi3);
 }
 
