@@ -232,8 +232,8 @@ PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
     R rmb = d_recip(mbar);
     R m1 = (mbar - 1.0) * rmb;
     R m2 = m1 * ((mbar - 2.0) * rmb);
-    R I1 = horner<7>(A0, zeta3) + m1 * horner<7>(A1, zeta3) + m2 * horner<7>(A2, zeta3);
-    R I2 = horner<7>(B0, zeta3) + m1 * horner<7>(B1, zeta3) + m2 * horner<7>(B2, zeta3);
+    R I1 = horner_zeta<7>(A0, zeta3) + m1 * horner_zeta<7>(A1, zeta3) + m2 * horner_zeta<7>(A2, zeta3);
+    R I2 = horner_zeta<7>(B0, zeta3) + m1 * horner_zeta<7>(B1, zeta3) + m2 * horner_zeta<7>(B2, zeta3);
     R z3m4 = z3m2 * z3m2;
     R t2 = z3m1 * d_recip(2.0 - zeta3);
     R poly = zeta3 * (20.0 + zeta3 * (-27.0 + zeta3 * (12.0 - 2.0 * zeta3)));
@@ -244,9 +244,9 @@ PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
 
     // dipoles
     if (c.polar) {
-        R phi2 = r00 * horner<5>(c.pj[0], zeta3) + r01 * horner<5>(c.pj[1], zeta3) + r11 * horner<5>(c.pj[2], zeta3);
-        R phi3 = (r00 * r0) * horner<4>(c.tj[0], zeta3) + (r00 * r1) * horner<4>(c.tj[1], zeta3) +
-                 (r0 * r11) * horner<4>(c.tj[2], zeta3) + (r11 * r1) * horner<4>(c.tj[3], zeta3);
+        R phi2 = r00 * horner_zeta<5>(c.pj[0], zeta3) + r01 * horner_zeta<5>(c.pj[1], zeta3) + r11 * horner_zeta<5>(c.pj[2], zeta3);
+        R phi3 = (r00 * r0) * horner_zeta<4>(c.tj[0], zeta3) + (r00 * r1) * horner_zeta<4>(c.tj[1], zeta3) +
+                 (r0 * r11) * horner_zeta<4>(c.tj[2], zeta3) + (r11 * r1) * horner_zeta<4>(c.tj[3], zeta3);
         // phi2 = phi3 = 0 where no polar component is present (pure-component limit next to a polar partner): the
         // quotient's limit is phi2 + O(rho_polar^3) (value and gradient 0, Hessian that of phi2)
         if (re(phi2) == 0.0) a = a + phi2;
@@ -268,8 +268,8 @@ PCS_DEV void dispersion_factors(const C& c, const R& r0, const R& r1, R& F1, R& 
     R rmb = d_recip(mbar);
     R m1 = (mbar - 1.0) * rmb;
     R m2 = m1 * ((mbar - 2.0) * rmb);
-    R I1 = horner<7>(A0, zeta3) + m1 * horner<7>(A1, zeta3) + m2 * horner<7>(A2, zeta3);
-    R I2 = horner<7>(B0, zeta3) + m1 * horner<7>(B1, zeta3) + m2 * horner<7>(B2, zeta3);
+    R I1 = horner_zeta<7>(A0, zeta3) + m1 * horner_zeta<7>(A1, zeta3) + m2 * horner_zeta<7>(A2, zeta3);
+    R I2 = horner_zeta<7>(B0, zeta3) + m1 * horner_zeta<7>(B1, zeta3) + m2 * horner_zeta<7>(B2, zeta3);
     R z3m4 = z3m2 * z3m2;
     R t2 = z3m1 * d_recip(2.0 - zeta3);
     R poly = zeta3 * (20.0 + zeta3 * (-27.0 + zeta3 * (12.0 - 2.0 * zeta3)));

@@ -98,6 +98,37 @@ PCS_DEV R horner(const P* coef, const R& x) {
     return acc;
 }
 
+// Horner in a two-variable Taylor type (mixture / gc evaluations): P, P', P''/2 by the three-term recurrence in the
+// value type T (3 FMA per coefficient, one dependent FMA per step) and ONE chain rule at the end, instead of a full
+// T2 (T1) product per coefficient (~15 (5) multiply-adds, three dependent).  N >= 3.
+template <int N, class P, class T>
+PCS_DEV T2<T> horner_zeta(const P* coef, const T2<T>& x) {
+    T d2 = T(coef[N - 1]);
+    T d1 = d2 * x.v + coef[N - 2];
+    T p = d1 * x.v + coef[N - 3];
+    d1 = d2 * x.v + d1;
+#pragma unroll
+    for (int i = N - 4; i >= 0; i--) {
+        d2 = d2 * x.v + d1;
+        d1 = d1 * x.v + p;
+        p = p * x.v + coef[i];
+    }
+    return x.chain(p, d1, 2.0 * d2);
+}
+template <int N, class P, class T>
+PCS_DEV T1<T> horner_zeta(const P* coef, const T1<T>& x) {
+    T d1 = T(coef[N - 1]);
+    T p = d1 * x.v + coef[N - 2];
+#pragma unroll
+    for (int i = N - 3; i >= 0; i--) {
+        d1 = d1 * x.v + p;
+        p = p * x.v + coef[i];
+    }
+    return x.chain(p, d1);
+}
+template <int N, class P, class R>
+PCS_DEV R horner_zeta(const P* coef, const R& x) { return horner<N>(coef, x); }
+
 // Horner for the solver's R = D2<double> when x.d2 == 0 structurally (x = eta = ceta * rho):
 // P, P', P'' by the three-term recurrence (3 FMA per coefficient instead of a full D2 product).
 template <int N>
