@@ -296,6 +296,10 @@ template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator+(const T& b, const T1<T
 template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator-(const T1<T>& a, const T& b) { return T1<T>(a.v - b, a.g0, a.g1); }
 template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator-(const T& b, const T1<T>& a) { return T1<T>(b - a.v, -a.g0, -a.g1); }
 
+// second-order <-> first-order two-variable types (drop / zero the Hessian part)
+template <class T> PCS_DEV T1<T> lower(const T2<T>& a) { return T1<T>(a.v, a.g0, a.g1); }
+template <class T> PCS_DEV T2<T> raise(const T1<T>& a) { return T2<T>(a.v, a.g0, a.g1, T(0.0), T(0.0), T(0.0)); }
+
 // ---- lifting a parameter-type value P into a result type R -------------------------------
 // Model code is templated on <P, R>: P is the type of parameters / temperature-only
 // coefficients (double in the solvers, a dual in the gradient kernels), R the type of the

@@ -200,6 +200,29 @@ PCS_DEV void gc_cross_step(const X& x0, const X& x1, const X& d00, const X& d01,
     dx1 = (j00 * f1 - j10 * f0) * rdet;
 }
 
+// see cross_refine (mix_model.hpp)
+template <class R>
+PCS_DEV void gc_cross_refine(R& xa0, R& xa1, const R& d00, const R& d01, const R& d10, const R& d11) {
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        R dx0, dx1;
+        gc_cross_step<R>(xa0, xa1, d00, d01, d10, d11, dx0, dx1);
+        xa0 = xa0 - dx0;
+        xa1 = xa1 - dx1;
+    }
+}
+template <class T>
+PCS_DEV void gc_cross_refine(T2<T>& xa0, T2<T>& xa1, const T2<T>& d00, const T2<T>& d01, const T2<T>& d10, const T2<T>& d11) {
+    T1<T> y0 = lower(xa0), y1 = lower(xa1), s0, s1;
+    gc_cross_step<T1<T>>(y0, y1, lower(d00), lower(d01), lower(d10), lower(d11), s0, s1);
+    xa0 = raise(y0 - s0);
+    xa1 = raise(y1 - s1);
+    T2<T> dx0, dx1;
+    gc_cross_step<T2<T>>(xa0, xa1, d00, d01, d10, d11, dx0, dx1);
+    xa0 = xa0 - dx0;
+    xa1 = xa1 - dx1;
+}
+
 template <class P, class R>
 PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
     Packing<R> pk;
@@ -260,13 +283,7 @@ PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
                 if (conv) break;
             }
             R xa0 = lift_real<R>(x0), xa1 = lift_real<R>(x1);
-#pragma unroll 1
-            for (int k = 0; k < 2; k++) {
-                R dx0, dx1;
-                gc_cross_step<R>(xa0, xa1, d00, d01, d10, d11, dx0, dx1);
-                xa0 = xa0 - dx0;
-                xa1 = xa1 - dx1;
-            }
+            gc_cross_refine(xa0, xa1, d00, d01, d10, d11);
             a = a + r0 * (2.0 * d_log(xa0) - xa0 + 1.0) + r1 * (2.0 * d_log(xa1) - xa1 + 1.0);  // :379-380
         } else {
             double n0 = re(c.na[0]), n1 = re(c.na[1]), m0 = re(c.nb[0]), m1n = re(c.nb[1]);
@@ -284,12 +301,7 @@ PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
             }
             R xa = lift_real<R>(x);
             R na0 = Lift<R, P>::go(c.na[0]), na1 = Lift<R, P>::go(c.na[1]), nb0 = Lift<R, P>::go(c.nb[0]), nb1 = Lift<R, P>::go(c.nb[1]);
-#pragma unroll 1
-            for (int k = 0; k < 2; k++) {
-                R f, dx;
-                induced_step<R>(xa, na0, na1, nb0, nb1, d00, d01, d10, d11, f, dx);
-                xa = xa - dx;
-            }
+            induced_refine(xa, na0, na1, nb0, nb1, d00, d01, d10, d11);
             R xb0 = d_recip(1.0 + xa * (na0 * d00 + na1 * d01));
             R xb1 = d_recip(1.0 + xa * (na0 * d10 + na1 * d11));
             R sa_ = site_term(xa);

@@ -286,6 +286,10 @@ __global__ __launch_bounds__(64) void k_mix_bubble_dew_queue(const double* __res
     MixModel m;
     int64_t row = -1;
     double T = 0.0;
+#if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
+    int nev = 0, t_start = 0;  // diagnostics: evaluations of this lane's row, kernel-relative start time
+    const long long t_kernel = clock64();
+#endif
     for (;;) {
         // hand rows to the lanes that have none
         unsigned long long need = __ballot(L.done());
@@ -308,6 +312,10 @@ __global__ __launch_bounds__(64) void k_mix_bubble_dew_queue(const double* __res
                 T = temp[row];
                 mix_coef<double>(m.c, par, k0, k1, T);
                 L.start(m, z[row], p_init[row] / (T * P_UNIT));
+#if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
+                nev = 0;
+                t_start = (int)((clock64() - t_kernel) >> 14);
+#endif
             }
             const int wanted = __popcll(need);
             next += wanted < avail ? wanted : avail;
@@ -319,6 +327,10 @@ __global__ __launch_bounds__(64) void k_mix_bubble_dew_queue(const double* __res
             L.point(e0, e1);
             PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
             L.consume(m, e);
+#if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
+            nev++;
+            if (L.done()) L.out.iters = (nev & 4095) | ((t_start & 0xffff) << 12);
+#endif
             if (L.done()) mix_store<DEW>(row, L.rc, L.out, T, p_out, rho4, status, iters);
         }
     }

@@ -201,6 +201,52 @@ PCS_DEV void induced_step(const X& xa, const X& na0, const X& na1, const X& nb0,
 template <class R>
 PCS_DEV R lift_real(double x) { return R(x); }
 
+// Derivatives of the site fractions: Newton updates in R arithmetic starting from the converged real parts.  Update k
+// makes the k-th derivatives exact, so first-order types would need one and second-order types two; the generic form
+// runs two.  For R = T2 the first update only has to produce the gradient and runs in T1 arithmetic (a third of the
+// multiply-adds of a T2 update; the cross-association step is ~45 products).
+template <class R>
+PCS_DEV void cross_refine(R& xa0, R& xa1, const R& A0, const R& A1, const R& B0, const R& B1, const R& d00, const R& d01, const R& d11) {
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        R dx0, dx1;
+        cross_step<R>(xa0, xa1, A0, A1, B0, B1, d00, d01, d11, dx0, dx1);
+        xa0 = xa0 - dx0;
+        xa1 = xa1 - dx1;
+    }
+}
+template <class T>
+PCS_DEV void cross_refine(T2<T>& xa0, T2<T>& xa1, const T2<T>& A0, const T2<T>& A1, const T2<T>& B0, const T2<T>& B1, const T2<T>& d00,
+                          const T2<T>& d01, const T2<T>& d11) {
+    T1<T> y0 = lower(xa0), y1 = lower(xa1), s0, s1;
+    cross_step<T1<T>>(y0, y1, lower(A0), lower(A1), lower(B0), lower(B1), lower(d00), lower(d01), lower(d11), s0, s1);
+    xa0 = raise(y0 - s0);
+    xa1 = raise(y1 - s1);
+    T2<T> dx0, dx1;
+    cross_step<T2<T>>(xa0, xa1, A0, A1, B0, B1, d00, d01, d11, dx0, dx1);
+    xa0 = xa0 - dx0;
+    xa1 = xa1 - dx1;
+}
+template <class R>
+PCS_DEV void induced_refine(R& xa, const R& na0, const R& na1, const R& nb0, const R& nb1, const R& d00, const R& d01, const R& d10, const R& d11) {
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        R f, dx;
+        induced_step<R>(xa, na0, na1, nb0, nb1, d00, d01, d10, d11, f, dx);
+        xa = xa - dx;
+    }
+}
+template <class T>
+PCS_DEV void induced_refine(T2<T>& xa, const T2<T>& na0, const T2<T>& na1, const T2<T>& nb0, const T2<T>& nb1, const T2<T>& d00,
+                            const T2<T>& d01, const T2<T>& d10, const T2<T>& d11) {
+    T1<T> y = lower(xa), f1, s;
+    induced_step<T1<T>>(y, lower(na0), lower(na1), lower(nb0), lower(nb1), lower(d00), lower(d01), lower(d10), lower(d11), f1, s);
+    xa = raise(y - s);
+    T2<T> f, dx;
+    induced_step<T2<T>>(xa, na0, na1, nb0, nb1, d00, d01, d10, d11, f, dx);
+    xa = xa - dx;
+}
+
 // Packing-fraction quantities shared by all contributions
 template <class R>
 struct Packing {
@@ -356,13 +402,7 @@ PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
                 if (conv) break;
             }
             R xa0 = lift_real<R>(x0), xa1 = lift_real<R>(x1);
-#pragma unroll 1
-            for (int k = 0; k < 2; k++) {  // two Newton updates in R arithmetic: 1st and 2nd derivatives
-                R dx0, dx1;
-                cross_step<R>(xa0, xa1, A0, A1, B0, B1, D[0], D[1], D[2], dx0, dx1);
-                xa0 = xa0 - dx0;
-                xa1 = xa1 - dx1;
-            }
+            cross_refine(xa0, xa1, A0, A1, B0, B1, D[0], D[1], D[2]);  // 1st and 2nd derivatives
             R xb0 = d_recip(1.0 + xa0 * (A0 * D[0]) + xa1 * (A1 * D[1]));
             R xb1 = d_recip(1.0 + xa0 * (A0 * D[1]) + xa1 * (A1 * D[2]));
             a = a + A0 * site_term(xa0) + A1 * site_term(xa1) + B0 * site_term(xb0) + B1 * site_term(xb1);
@@ -385,12 +425,7 @@ PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
             }
             R xa = lift_real<R>(x);
             R na0 = Lift<R, P>::go(c.na[0]), na1 = Lift<R, P>::go(c.na[1]), nb0 = Lift<R, P>::go(c.nb[0]), nb1 = Lift<R, P>::go(c.nb[1]);
-#pragma unroll 1
-            for (int k = 0; k < 2; k++) {
-                R f, dx;
-                induced_step<R>(xa, na0, na1, nb0, nb1, d00, d01, d10, d11, f, dx);
-                xa = xa - dx;
-            }
+            induced_refine(xa, na0, na1, nb0, nb1, d00, d01, d10, d11);
             R xb0 = d_recip(1.0 + xa * (na0 * d00 + na1 * d01));
             R xb1 = d_recip(1.0 + xa * (na0 * d10 + na1 * d11));
             R sa = site_term(xa);

@@ -140,7 +140,12 @@ PCS_DEV bool solve3(double A[3][4], double* x) {
 // runs that have not settled after SS_MAX_IT sweeps.  The CPU oracle uses the same caps.
 constexpr int SS_MAX_IT = 40;
 constexpr double SS_TOL = 1e-5;        // composition change at which the dew-point successive substitution hands over to Newton
-constexpr int NEWTON_NO_PROGRESS = 30; // Newton iterations without a new smallest step before the row is given up
+// A Newton iteration whose largest step has not shrunk by NEWTON_PROGRESS (relative to the smallest one so far) within
+// NEWTON_NO_PROGRESS iterations is given up: it cycles (typically a 2-cycle whose amplitude creeps down by 1e-3 per
+// round: no phase equilibrium at this state).  Bubble points start next to the solution (liquid root + ideal vapour)
+// and get the shorter leash; measured on the synthetic batches no converging row is lost by either.
+constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;
+constexpr double NEWTON_PROGRESS = 0.9;
 constexpr int NEWTON_MAX_IT = 60;
 
 struct MixResult {
@@ -199,7 +204,7 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
             x0 = z0;
             x1 = z1;
         }
-        double rl = 0.0, xi_prev = 0.0, res_prev = 0.0;
+        double rl = 0.0, xi_prev = 0.0, res_prev = 0.0, xi_lo = -1e300, xi_hi = 1e300;
         bool settled = false, have = false;
         for (int ss = 0; ss < ss_max; ss++) {
             // The liquid density is not re-solved in every sweep: the evaluation at (x, rl) gives p and dp/drho along x,
@@ -241,6 +246,12 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
             double xi = log(x0 / x1);
             double res = log(n0 / n1) - xi;
             bool secant = false;
+            // Bracket of the fixed point: r > 0 at xi_lo, r < 0 at xi_hi (r decreases through a stable fixed point).  For
+            // strongly non-ideal liquids the map cycles around a steep or discontinuous stretch of r (the liquid root
+            // changes branch); an iterate that leaves the bracket is then replaced by its midpoint, and a bracket
+            // narrower than the tolerance ends the substitution.
+            if (res > 0.0 && xi > xi_lo) xi_lo = xi;
+            if (res < 0.0 && xi < xi_hi) xi_hi = xi;
             if (ss > 0 && xi != xi_prev) {
                 double slope = (res - res_prev) / (xi - xi_prev);
                 if (slope < -0.05) {
@@ -261,8 +272,18 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
                 x0 = n0 / s2;
                 x1 = n1 / s2;
             }
+            bool narrow = false;
+            if (xi_lo < xi_hi && xi_lo > -1e299 && xi_hi < 1e299) {
+                double xin = log(x0 / x1);
+                if (!(xin > xi_lo && xin < xi_hi)) {
+                    double e = exp(0.5 * (xi_lo + xi_hi));
+                    x0 = e / (1.0 + e);
+                    x1 = 1.0 / (1.0 + e);
+                }
+                narrow = xi_hi - xi_lo < SS_TOL;
+            }
             p0 = 1.0 / sum;
-            if (dx < SS_TOL) { settled = true; break; }
+            if (dx < SS_TOL || narrow) { settled = true; break; }
         }
         if (!settled && ss_max < SS_MAX_IT) return BD_CAP;
         ri0 = x0 * rl;
@@ -294,8 +315,8 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
         if (!is_finite_bits(mx)) return BD_FAILED;
         // no new smallest Newton step for NEWTON_NO_PROGRESS iterations: the iteration cycles / wanders (no phase
         // equilibrium at this state, or the EOS is ill-behaved there) -> fail now, not at the cap
-        if (mx < err_best) { err_best = mx; it_best = it; }
-        else if (it - it_best >= NEWTON_NO_PROGRESS) return BD_FAILED;
+        if (mx < NEWTON_PROGRESS * err_best) { err_best = mx; it_best = it; }
+        else if (it - it_best >= (DEW ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE)) return BD_FAILED;
         double scale = mx > 1.0 ? 1.0 / mx : 1.0;  // at most a factor e per iteration
         rs *= exp(scale * du[0]);
         ri0 *= exp(scale * du[1]);

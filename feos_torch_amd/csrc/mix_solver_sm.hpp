@@ -32,7 +32,7 @@ struct BdLane {
     bool r_dense, r_has_alt, r_warm;
     double r_x0, r_x1, r_pk, r_rho, r_pspec, r_palt, r_errprev;
     // dew initialisation
-    double f0, x0, x1, p0, rl, xi_prev, res_prev;
+    double f0, x0, x1, p0, rl, xi_prev, res_prev, xi_lo, xi_hi;
     int ss;
     bool resolved;
     // Newton
@@ -69,7 +69,7 @@ struct BdLane {
         z0 = z0_; z1 = 1.0 - z0_; p_init = p_init_;
         ss_max = ss_max_; newton_max = newton_max_;
         rc = BD_FAILED;
-        f0 = 0.0; x0 = z0; x1 = z1; p0 = p_init; rl = 0.0; xi_prev = 0.0; res_prev = 0.0;
+        f0 = 0.0; x0 = z0; x1 = z1; p0 = p_init; rl = 0.0; xi_prev = 0.0; res_prev = 0.0; xi_lo = -1e300; xi_hi = 1e300;
         ss = 0;
         resolved = false;
         rs = 0.0; ri0 = 0.0; ri1 = 0.0; err_prev = 1.0; err_best = 1e300;
@@ -182,6 +182,9 @@ struct BdLane {
             const double xi = log(x0 / x1);
             const double res = log(n0 / n1) - xi;
             bool secant = false;
+            // bracket of the fixed point: r > 0 at xi_lo, r < 0 at xi_hi (see mix_solver.hpp)
+            if (res > 0.0 && xi > xi_lo) xi_lo = xi;
+            if (res < 0.0 && xi < xi_hi) xi_hi = xi;
             if (ss > 0 && xi != xi_prev) {
                 const double slope = (res - res_prev) / (xi - xi_prev);
                 if (slope < -0.05) {
@@ -201,9 +204,19 @@ struct BdLane {
                 x0 = n0 / s2;
                 x1 = n1 / s2;
             }
+            bool narrow = false;
+            if (xi_lo < xi_hi && xi_lo > -1e299 && xi_hi < 1e299) {
+                const double xin = log(x0 / x1);
+                if (!(xin > xi_lo && xin < xi_hi)) {
+                    const double ee = exp(0.5 * (xi_lo + xi_hi));
+                    x0 = ee / (1.0 + ee);
+                    x1 = 1.0 / (1.0 + ee);
+                }
+                narrow = xi_hi - xi_lo < SS_TOL;
+            }
             p0 = 1.0 / sum;
             ss++;
-            const bool settled = dx < SS_TOL;
+            const bool settled = dx < SS_TOL || narrow;
             if (settled || ss >= ss_max) {
                 if (!settled && ss_max < SS_MAX_IT) { rc = BD_CAP; stage = S_DONE; return; }
                 ri0 = x0 * rl;
@@ -240,8 +253,8 @@ struct BdLane {
             if (!solve3(A, du)) { stage = S_DONE; return; }
             const double mx = fmax(fabs(du[0]), fmax(fabs(du[1]), fabs(du[2])));
             if (!is_finite_bits(mx)) { stage = S_DONE; return; }
-            if (mx < err_best) { err_best = mx; it_best = it; }
-            else if (it - it_best >= NEWTON_NO_PROGRESS) { stage = S_DONE; return; }
+            if (mx < NEWTON_PROGRESS * err_best) { err_best = mx; it_best = it; }
+            else if (it - it_best >= (DEW ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE)) { stage = S_DONE; return; }
             const double scale = mx > 1.0 ? 1.0 / mx : 1.0;
             rs *= exp(scale * du[0]);
             ri0 *= exp(scale * du[1]);

@@ -67,7 +67,8 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
 // the scaled function is nearly linear).  Only used to initialise the phase-equilibrium Newton, so
 // a relative step of LIQ_ROOT_TOL suffices.  Same logic and caps as csrc/mix_solver.hpp.
 constexpr double LIQ_ROOT_TOL = 1e-6;
-constexpr int NEWTON_NO_PROGRESS = 30;
+constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
+constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point successive substitution hands over to Newton
 template <class F, class Model>
 bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out, F rho_start = F(0)) {
@@ -169,6 +170,9 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         static const bool ss_secant = getenv("ORC_SS_PLAIN") == nullptr;
         static const bool ss_track = getenv("ORC_SS_NOTRACK") == nullptr;
         F xi_prev = 0, res_prev = 0;
+        // bracket of the fixed point in xi: r > 0 at xi_lo, r < 0 at xi_hi (r decreases through a stable fixed point)
+        static const bool ss_bracket = getenv("ORC_SS_NOBRACKET") == nullptr;
+        F xi_lo = F(-1e300), xi_hi = F(1e300);
         static const int ss_cap = getenv("ORC_SS_CAP") ? atoi(getenv("ORC_SS_CAP")) : 40;
         static const double ss_tol = getenv("ORC_SS_TOL") ? atof(getenv("ORC_SS_TOL")) : SS_TOL;
         for (int ss = 0; ss < ss_cap; ss++) {  // same caps as the kernels (csrc/mix_solver.hpp)
@@ -212,6 +216,10 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             F xi = log(x[0] / x[1]);
             F res = log(xn[0] / xn[1]) - xi;
             bool secant = false;
+            if (ss_bracket) {
+                if (res > F(0) && xi > xi_lo) xi_lo = xi;
+                if (res < F(0) && xi < xi_hi) xi_hi = xi;
+            }
             if (ss_secant && ss > 0 && xi != xi_prev) {
                 F slope = (res - res_prev) / (xi - xi_prev);
                 if (slope < F(-0.05)) {
@@ -238,9 +246,21 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
                 x[0] = xn[0] / s2;
                 x[1] = xn[1] / s2;
             }
+            bool narrow = false;
+            if (ss_bracket && xi_lo < xi_hi && xi_lo > F(-1e299) && xi_hi < F(1e299)) {
+                // the map cycles around a steep (or discontinuous: the liquid root changes branch) stretch of r(xi):
+                // an iterate outside the bracket is replaced by its midpoint
+                F xin = log(x[0] / x[1]);
+                if (!(xin > xi_lo && xin < xi_hi)) {
+                    F e = exp(F(0.5) * (xi_lo + xi_hi));
+                    x[0] = e / (F(1) + e);
+                    x[1] = F(1) / (F(1) + e);
+                }
+                narrow = xi_hi - xi_lo < F(ss_tol);
+            }
             p0 = F(1) / sum;
             if (getenv("ORC_TRACE")) fprintf(stderr, "ss %d x %.6e %.6e p0 %.6e rl %.6e dx %.3e\n", ss, (double)x[0], (double)x[1], (double)p0, (double)rl, (double)dx);
-            if (dx < F(ss_tol)) break;
+            if (dx < F(ss_tol) || narrow) break;
         }
         if (!have) return false;
         if (!ss_track && !liquid_root<F>(model, T, x, p0, rl) && !liquid_root<F>(model, T, x, F(0), rl)) return false;
@@ -251,7 +271,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
     // Newton in (ln rho_spec, ln rho_inc_1, ln rho_inc_2)
     F err_prev = F(1), err_best = F(1e300);
     int it_best = 0;
-    static const int no_progress = getenv("ORC_NP") ? atoi(getenv("ORC_NP")) : NEWTON_NO_PROGRESS;
+    const int no_progress = getenv("ORC_NP") ? atoi(getenv("ORC_NP")) : (dew ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE);
     for (int it = 0; it < 60; it++) {
         F r_s[2] = {z[0] * rs, z[1] * rs};
         PhaseEval<F> s = eval_phase<F>(model, T, r_s);
@@ -273,7 +293,8 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         if (!(mx == mx)) return false;
         // no new smallest Newton step for NEWTON_NO_PROGRESS iterations: the iteration cycles / wanders
         // (no phase equilibrium at this state, or the EOS is ill-behaved there) -> fail now, not at the cap
-        if (mx < err_best) { err_best = mx; it_best = it; }
+        static const double np_factor = getenv("ORC_NP_FACTOR") ? atof(getenv("ORC_NP_FACTOR")) : NEWTON_PROGRESS;
+        if (mx < F(np_factor) * err_best) { err_best = mx; it_best = it; }
         else if (it - it_best >= no_progress) return false;
         F scale = mx > F(1) ? F(1) / mx : F(1);  // at most a factor e per iteration
         rs = rs * exp(scale * du[0]);

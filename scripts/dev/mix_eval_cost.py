@@ -17,6 +17,9 @@ def t(fn, reps=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return np.median(ts)
+from feos_torch_amd import _lib
+if len(sys.argv) > 1:  # variant library scratch/ab/lib_<name>.so
+    _lib.LIB_PATH = os.path.abspath(f"scratch/ab/lib_{sys.argv[1]}.so"); _lib._lib = None
 ms = t(lambda: native.mix_derivatives(a[0], a[1], a[2], rho))
 print(f"k_mix_derivatives (1 T2 evaluation per row, liquid densities) 1e6 rows: {ms:.3f} ms -> {ms*1e-3*2.4e9*1024/ (n/64):.0f} SIMD-cycles per wave-evaluation")
 for c in range(6):
