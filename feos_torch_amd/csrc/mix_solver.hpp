@@ -61,7 +61,9 @@ PCS_EVAL_ATTR void line_eval(const Model& m, double x0, double x1, double rho, d
     dp = 1.0 + rho * r.d2;
 }
 
-constexpr double LIQ_ROOT_TOL = 1e-6;  // relative step; the roots only initialise the phase-equilibrium Newton
+// relative step at which a liquid root is accepted.  The roots only initialise the substitution / the Newton, and the
+// state machine carries the chemical potentials to the root to first order: 1e-3 leaves a 1e-6 error
+constexpr double LIQ_ROOT_TOL = 1e-3;
 constexpr int LIQ_ROOT_MAX_IT = 30;  // Newton from the dense side needs ~5-10; a row that needs more fails
 
 // liquid-like root of p(rho) = p_spec at composition x.  Cold start: Newton from the dense side
@@ -328,11 +330,11 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
             double dens_i = ri0 + ri1;
             double lo = DEW ? rs : dens_i, hi = DEW ? dens_i : rs;
             if (!(lo < hi * (1.0 - 1e-6))) return BD_FAILED;  // trivial solution
-            // final evaluation at the converged state -> reference formula
-            PhaseEval sf = phase_eval(m, z0 * rs, z1 * rs);
-            PhaseEval nf = phase_eval(m, ri0, ri1);
-            out.spec0 = sf.r0; out.spec1 = sf.r1; out.inc0 = ri0; out.inc1 = ri1;
-            out.p = bubble_dew_formula(sf, nf);
+            // converged: the state of this iteration's evaluations is within mx of the solution and the reference's
+            // final formula is second order in that error, so it is applied to them directly; the densities handed
+            // out carry the last step
+            out.spec0 = z0 * rs; out.spec1 = z1 * rs; out.inc0 = ri0; out.inc1 = ri1;
+            out.p = bubble_dew_formula(s, n);
             return is_finite_bits(out.p) ? BD_OK : BD_FAILED;
         }
     }

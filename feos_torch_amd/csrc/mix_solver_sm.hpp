@@ -22,7 +22,7 @@ namespace pcs {
 // Per-lane solver state.  start() -> { point(); e = phase_eval(...); consume(e); } until done().
 template <bool DEW>
 struct BdLane {
-    enum : int { S_ROOT, S_SS, S_NEWTON_S, S_NEWTON_N, S_FINAL_S, S_FINAL_N, S_DONE };
+    enum : int { S_ROOT, S_SS, S_NEWTON_S, S_NEWTON_N, S_DONE };
     enum : int { R_PURE0, R_PURE1, R_SS, R_BUBBLE };  // who asked for the liquid root
     int stage, rc;
     double z0, z1, p_init;
@@ -85,7 +85,7 @@ struct BdLane {
     PCS_DEV void point(double& e0, double& e1) const {
         if (stage == S_ROOT) { e0 = r_x0 * r_rho; e1 = r_x1 * r_rho; }
         else if (stage == S_SS) { e0 = x0 * rl; e1 = x1 * rl; }
-        else if (stage == S_NEWTON_S || stage == S_FINAL_S) { e0 = z0 * rs; e1 = z1 * rs; }
+        else if (stage == S_NEWTON_S) { e0 = z0 * rs; e1 = z1 * rs; }
         else { e0 = ri0; e1 = ri1; }
     }
 
@@ -227,9 +227,9 @@ struct BdLane {
             return;
         }
 
-        if (stage == S_NEWTON_S || stage == S_FINAL_S) {
+        if (stage == S_NEWTON_S) {
             sv = e;
-            stage = (stage == S_NEWTON_S) ? S_NEWTON_N : S_FINAL_N;
+            stage = S_NEWTON_N;
             return;
         }
 
@@ -266,8 +266,14 @@ struct BdLane {
             if (mx <= 1e-9 || stagnated) {
                 const double dens_i = ri0 + ri1;
                 const double lo = DEW ? rs : dens_i, hi = DEW ? dens_i : rs;
-                if (!(lo < hi * (1.0 - 1e-6))) { stage = S_DONE; return; }  // trivial solution
-                stage = S_FINAL_S;
+                stage = S_DONE;
+                if (!(lo < hi * (1.0 - 1e-6))) return;  // trivial solution
+                // converged: the state these two evaluations were taken at is within mx of the solution and the
+                // reference's final formula is second order in that error, so it is applied to them directly (no
+                // further evaluation); the densities handed out carry the last step
+                out.spec0 = z0 * rs; out.spec1 = z1 * rs; out.inc0 = ri0; out.inc1 = ri1;
+                out.p = bubble_dew_formula(s, n);
+                rc = is_finite_bits(out.p) ? BD_OK : BD_FAILED;
             } else if (it >= newton_max) {
                 rc = (newton_max < NEWTON_MAX_IT) ? BD_CAP : BD_FAILED;
                 stage = S_DONE;
@@ -277,11 +283,6 @@ struct BdLane {
             return;
         }
 
-        // S_FINAL_N: both phases evaluated at the converged state -> reference formula
-        out.spec0 = sv.r0; out.spec1 = sv.r1; out.inc0 = ri0; out.inc1 = ri1;
-        out.p = bubble_dew_formula(sv, e);
-        rc = is_finite_bits(out.p) ? BD_OK : BD_FAILED;
-        stage = S_DONE;
 #undef PCS_SM_START_ROOT
 #undef PCS_SM_START_ROOT_WARM
     }

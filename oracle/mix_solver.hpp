@@ -66,7 +66,7 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
 // The iteration runs on (p - p_spec)(1 - eta)^4 = 0 (same root; the hard-sphere pole makes p steep,
 // the scaled function is nearly linear).  Only used to initialise the phase-equilibrium Newton, so
 // a relative step of LIQ_ROOT_TOL suffices.  Same logic and caps as csrc/mix_solver.hpp.
-constexpr double LIQ_ROOT_TOL = 1e-6;
+constexpr double LIQ_ROOT_TOL = 1e-3;  // as csrc/mix_solver.hpp
 constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
 constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point successive substitution hands over to Newton
