@@ -126,6 +126,11 @@ template <class T> PCS_DEV D1<T> operator*(double b, const D1<T>& a) { return D1
 template <class T> PCS_DEV D1<T> d_recip(const D1<T>& a) { T r = d_recip(a.v); return a.chain(r, -(r * r)); }
 template <class T> PCS_DEV D1<T> d_log(const D1<T>& a) { return a.chain(d_log(a.v), d_recip(a.v)); }
 template <class T> PCS_DEV D1<T> d_sqrt(const D1<T>& a) { T sq = d_sqrt(a.v); return a.chain(sq, 0.5 * d_recip(sq)); }
+template <class T> PCS_DEV D1<T> d_exp(const D1<T>& a) { T e = d_exp(a.v); return a.chain(e, e); }
+template <class T> PCS_DEV D1<T> d_cbrt(const D1<T>& a) { T s = d_cbrt(a.v); return a.chain(s, s * d_recip(a.v) * (1.0 / 3.0)); }
+template <class T> PCS_DEV D1<T> operator/(const D1<T>& a, const D1<T>& b) { return a * d_recip(b); }
+template <class T> PCS_DEV D1<T> operator/(const D1<T>& a, double b) { double r = 1.0 / b; return a * r; }
+template <class T> PCS_DEV D1<T> operator/(double b, const D1<T>& a) { return d_recip(a) * b; }
 template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator*(const D1<T>& a, const T& b) { return D1<T>(a.v * b, a.d1 * b); }
 template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator*(const T& b, const D1<T>& a) { return D1<T>(a.v * b, a.d1 * b); }
 template <class T, PCS_IFDUAL(T)> PCS_DEV D1<T> operator+(const D1<T>& a, const T& b) { return D1<T>(a.v + b, a.d1); }
@@ -308,6 +313,7 @@ template <class R, class P> struct Lift;
 template <class R> struct Lift<R, R> { static PCS_DEV const R& go(const R& p) { return p; } };
 template <class T> struct Lift<D2<T>, double> { static PCS_DEV D2<T> go(double p) { return D2<T>(p); } };
 template <class T, int N> struct Lift<DN<T, N>, double> { static PCS_DEV DN<T, N> go(double p) { return DN<T, N>(p); } };
+template <class T> struct Lift<D1<T>, T> { static PCS_DEV D1<T> go(const T& p) { return D1<T>(p, T(0.0)); } };
 template <class T> struct Lift<T1<T>, T> { static PCS_DEV T1<T> go(const T& p) { return T1<T>(p, T(0.0), T(0.0)); } };
 template <class T> struct Lift<T2<T>, double> { static PCS_DEV T2<T> go(double p) { return T2<T>(p); } };
 

@@ -7,8 +7,10 @@
 // applied directly at the converged state u = (ln rho_spec, ln rho_inc_0, ln rho_inc_1):
 //     F(u, theta) = (mu_0^S - mu_0^I, mu_1^S - mu_1^I, p^S - p^I) = 0,   p = p^S(u, theta)
 //     dp/dtheta = dp^vap/dtheta|_u - w . dF/dtheta|_u,      J^T w = dp^vap/du   (vap = vapour phase)
-// J comes from one T2<double> evaluation per phase (as in the solver); the explicit parameter
-// derivatives d(a, da/drho_i)/dtheta from T1<DN<double,C>> evaluations, C directions per pass.
+// J comes from one T2<double> evaluation per phase (as in the solver).  The explicit parameter derivatives enter only
+// through one scalar per phase, alpha a + beta . grad_rho a with row constants (alpha, beta) made of w and the
+// densities, so each phase needs d/dtheta of a and of ONE directional derivative of a: D1<DN<double,C>> evaluations
+// along beta (4 numbers per quantity for C = 1 instead of the 6 of a full gradient), C directions per pass.
 #pragma once
 #include "mix_model.hpp"
 #include "mix_solver.hpp"
@@ -17,7 +19,10 @@ namespace pcs {
 
 constexpr int MIX_DIRS = 19;  // 16 parameters (component 0 then 1), k_ij, eps_AiBj, T
 #ifndef PCS_MIX_CHUNK
-#define PCS_MIX_CHUNK 1  // directions per pass; A/B on 1e6 rows: 1: 35 ms, 2: 41, 3: 47, 4: 54 (register pressure)
+// directions per pass; A/B on 1e6 rows: 1: 13.3 ms, 2: 9.8 ms, 3: 10.4 ms.  The kernel's stack frame (coefficient struct
+// with tangents + spills) must stay small: at 2.5-4 KB per lane the runtime throttles the resident waves (measured:
+// 21 ms, and bimodal with the launch history); with the coefficient set-up out of line it is 2.2 KB for 2 directions
+#define PCS_MIX_CHUNK 2
 #endif
 constexpr int MIX_CHUNK = PCS_MIX_CHUNK;
 
@@ -30,6 +35,27 @@ struct MixModelD {
 template <class G, class R>
 __device__ __attribute__((noinline)) R mix_a_tangent(const MixCoef<G>& c, const R& r0, const R& r1) {
     return mix_a<G, R>(c, r0, r1);
+}
+
+// coefficients with their parameter tangents for direction(s) d0 .. d0 + MIX_CHUNK - 1; out of line so that its
+// register spills live in its own stack frame (which the evaluation's frame then reuses) instead of the kernel's
+template <class G>
+__device__ __attribute__((noinline)) void mix_coef_tangent(MixCoef<G>& c, const double* __restrict__ par, double k0, double k1, double T, int d0) {
+    G gp[16], gk0, gk1, gT;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        gp[k].v = par[k];
+#pragma unroll
+        for (int j = 0; j < MIX_CHUNK; j++) gp[k].e[j] = (d0 + j == k) ? 1.0 : 0.0;
+    }
+    gk0.v = k0; gk1.v = k1; gT.v = T;
+#pragma unroll
+    for (int j = 0; j < MIX_CHUNK; j++) {
+        gk0.e[j] = (d0 + j == 16) ? 1.0 : 0.0;
+        gk1.e[j] = (d0 + j == 17) ? 1.0 : 0.0;
+        gT.e[j] = (d0 + j == 18) ? 1.0 : 0.0;
+    }
+    mix_coef<G>(c, gp, gk0, gk1, gT);
 }
 
 // spec = (rho_spec_0, rho_spec_1), inc = (rho_inc_0, rho_inc_1); out[19] in Pa per unit of theta
@@ -71,7 +97,19 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
     bool ok = solve3(A, w);
     const double p_red = spec_is_vapor ? s.p() : n.p();
     typedef DN<double, MIX_CHUNK> G;
-    typedef T1<G> R;
+    typedef D1<G> R;
+    // dp/dtheta = sum over the two phases of d/dtheta [alpha a + beta . grad a]:
+    //   p^X = -a^X + rho^X . grad a^X,  F_i = grad_i a^S - grad_i a^I,  dp = dp^vap - (w0 F0 + w1 F1 + w2 (p^S - p^I))
+    double alpha[2], beta0[2], beta1[2];
+    if (spec_is_vapor) {
+        const double u = 1.0 - w[2];
+        alpha[0] = -u;     beta0[0] = u * s0 - w[0];     beta1[0] = u * s1 - w[1];
+        alpha[1] = -w[2];  beta0[1] = w[2] * i0 + w[0];  beta1[1] = w[2] * i1 + w[1];
+    } else {
+        const double u = 1.0 + w[2];
+        alpha[0] = w[2];   beta0[0] = -w[2] * s0 - w[0]; beta1[0] = -w[2] * s1 - w[1];
+        alpha[1] = -u;     beta0[1] = u * i0 + w[0];     beta1[1] = u * i1 + w[1];
+    }
     constexpr int NPASS = (MIX_DIRS + MIX_CHUNK - 1) / MIX_CHUNK;
     // directions whose derivative is structurally zero: a dipole moment of 0 (the term is quadratic in it), every
     // association parameter when no component associates (the term is absent), eps_AiBj unless it is in use
@@ -80,53 +118,42 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; pass++) {
         const int d0 = pass * MIX_CHUNK;
-        if (MIX_CHUNK == 1) {
-            const int kk = d0 & 7;
-            bool zero = false;
-            if (d0 < 16) zero = (kk == 3 && par[d0] == 0.0) || (kk >= 4 && no_assoc);
-            else if (d0 == 17) zero = !eab_used;
+        {
+            bool zero = true;  // every direction of this pass is structurally zero for this row
+#pragma unroll
+            for (int j = 0; j < MIX_CHUNK; j++) {
+                const int d = d0 + j, kk = d & 7;
+                bool zj = true;
+                if (d < 16) zj = (kk == 3 && par[d] == 0.0) || (kk >= 4 && no_assoc);
+                else if (d == 17) zj = !eab_used;
+                else if (d < MIX_DIRS) zj = false;
+                zero = zero && zj;
+            }
             if (__ballot(!zero) == 0ull) {  // the whole wave skips the pass
-                g[d0] = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+                for (int j = 0; j < MIX_CHUNK; j++)
+                    if (d0 + j < MIX_DIRS) g[d0 + j] = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
                 continue;
             }
         }
-        G gp[16], gk0, gk1, gT;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            gp[k].v = par[k];
-#pragma unroll
-            for (int j = 0; j < MIX_CHUNK; j++) gp[k].e[j] = (d0 + j == k) ? 1.0 : 0.0;
-        }
-        gk0.v = k0; gk1.v = k1; gT.v = T;
-#pragma unroll
-        for (int j = 0; j < MIX_CHUNK; j++) {
-            gk0.e[j] = (d0 + j == 16) ? 1.0 : 0.0;
-            gk1.e[j] = (d0 + j == 17) ? 1.0 : 0.0;
-            gT.e[j] = (d0 + j == 18) ? 1.0 : 0.0;
-        }
         MixCoef<G> c;
-        mix_coef<G>(c, gp, gk0, gk1, gT);
+        mix_coef_tangent<G>(c, par, k0, k1, T, d0);
         // both phases through ONE evaluation site (loop not unrolled, evaluation not inlined): the dual-number
         // evaluation is large, two inlined copies per pass cost ~5,000 spilled VGPRs
-        double av[2][MIX_CHUNK], ag0[2][MIX_CHUNK], ag1[2][MIX_CHUNK];
+        double acc[MIX_CHUNK];
+#pragma unroll
+        for (int j = 0; j < MIX_CHUNK; j++) acc[j] = 0.0;
 #pragma unroll 1
         for (int ph = 0; ph < 2; ph++) {
             const double q0 = ph == 0 ? s0 : i0, q1 = ph == 0 ? s1 : i1;
-            R a = mix_a_tangent<G, R>(c, R(G(q0), G(1.0), G(0.0)), R(G(q1), G(0.0), G(1.0)));
+            const double al = ph == 0 ? alpha[0] : alpha[1], b0 = ph == 0 ? beta0[0] : beta0[1], b1 = ph == 0 ? beta1[0] : beta1[1];
+            R a = mix_a_tangent<G, R>(c, R(G(q0), G(b0)), R(G(q1), G(b1)));
 #pragma unroll
-            for (int j = 0; j < MIX_CHUNK; j++) {
-                const double v = a.v.e[j], d0v = a.g0.e[j], d1v = a.g1.e[j];
-                if (ph == 0) { av[0][j] = v; ag0[0][j] = d0v; ag1[0][j] = d1v; }
-                else { av[1][j] = v; ag0[1][j] = d0v; ag1[1][j] = d1v; }
-            }
+            for (int j = 0; j < MIX_CHUNK; j++) acc[j] += al * a.v.e[j] + a.d1.e[j];
         }
 #pragma unroll
         for (int j = 0; j < MIX_CHUNK; j++) {
-            double dF0 = ag0[0][j] - ag0[1][j];
-            double dF1 = ag1[0][j] - ag1[1][j];
-            double dpS = -av[0][j] + s0 * ag0[0][j] + s1 * ag1[0][j];
-            double dpI = -av[1][j] + i0 * ag0[1][j] + i1 * ag1[1][j];
-            double dp = (spec_is_vapor ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
+            const double dp = acc[j];
             double val = dp * T * P_UNIT;
             if (d0 + j == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
             if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);

@@ -126,6 +126,17 @@ PCS_DEV T1<T> horner_zeta(const P* coef, const T1<T>& x) {
     }
     return x.chain(p, d1);
 }
+template <int N, class P, class T, PCS_IFDUAL(T)>
+PCS_DEV D1<T> horner_zeta(const P* coef, const D1<T>& x) {
+    T d1 = T(coef[N - 1]);
+    T p = d1 * x.v + coef[N - 2];
+#pragma unroll
+    for (int i = N - 3; i >= 0; i--) {
+        d1 = d1 * x.v + p;
+        p = p * x.v + coef[i];
+    }
+    return x.chain(p, d1);
+}
 template <int N, class P, class R>
 PCS_DEV R horner_zeta(const P* coef, const R& x) { return horner<N>(coef, x); }
 
