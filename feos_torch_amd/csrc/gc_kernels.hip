@@ -48,7 +48,13 @@ __device__ __forceinline__ GcTable stage_table(const double* __restrict__ table,
     return tb;
 }
 
-constexpr int GC_FAST_SS = 12, GC_FAST_NEWTON = 12;  // fast-pass caps (mix_solver.hpp)
+#ifndef PCS_GC_FAST_SS
+#define PCS_GC_FAST_SS 6  // A/B on the synthetic dew batch (scripts/dev/ab_gc.py): 12/12: 9.0 ms, 6/8: 7.9, 4/8: 8.4, 7/7: 8.6
+#endif
+#ifndef PCS_GC_FAST_NEWTON
+#define PCS_GC_FAST_NEWTON 8
+#endif
+constexpr int GC_FAST_SS = PCS_GC_FAST_SS, GC_FAST_NEWTON = PCS_GC_FAST_NEWTON;  // fast-pass caps (mix_solver.hpp)
 constexpr int GC_RETRY_BLOCKS = 1024;
 
 template <bool DEW>
