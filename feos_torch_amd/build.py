@@ -17,15 +17,44 @@ SOURCES = ["pure_kernels.hip", "pure_robust.hip", "mix_kernels.hip", "gc_kernels
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 RELAXED = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros", "-DPCS_FAST_RCP", "-DPCS_F32_PRESOLVE"]
 RELAXED_SOURCES = {"pure_kernels.hip"}
+RESOURCES = os.path.join(HERE, "build", "resources.json")  # per-kernel register / stack report of the last build
 
 
 def _stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(RESOURCES):
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "pcsaft_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _parse_resources(text):
+    """kernel-resource-usage remarks of one hipcc run -> {mangled name: {vgpr, agpr, scratch, occupancy}}"""
+    import re
+
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("vgpr", r"remark:\s+VGPRs: (\d+)"), ("agpr", r"remark:\s+AGPRs: (\d+)"),
+                         ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m:
+                cur[key] = int(m.group(1))
+    return out
+
+
+def _demangle(names):
+    try:
+        out = subprocess.run(["c++filt"] + names, capture_output=True, text=True, check=True).stdout.split("\n")
+        return dict(zip(names, out))
+    except Exception:
+        return {n: n for n in names}
 
 
 def build(force=False, verbose=False):
@@ -39,11 +68,25 @@ def build(force=False, verbose=False):
         cmd = ["hipcc"] + FLAGS + (RELAXED if s in RELAXED_SOURCES else []) + ["-c", "-o", obj, os.path.join(CSRC, s)]
         if verbose:
             print(" ".join(cmd))
-        procs.append(subprocess.Popen(cmd))
+        # the compiler's per-kernel register / stack report is kept next to the objects (tests/test_abi.py guards the
+        # stack frames: above ~2.5 KB per lane the runtime throttles the resident waves)
+        procs.append(subprocess.Popen(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True))
         objs.append(obj)
+    resources = {}
     for p in procs:
-        if p.wait() != 0:
+        _, err = p.communicate()
+        if p.returncode != 0:
+            print(err)
             raise subprocess.CalledProcessError(p.returncode, "hipcc")
+        resources.update(_parse_resources(err))
+        rest = [ln for ln in err.splitlines() if "kernel-resource-usage" not in ln and ("warning" in ln or "error" in ln)]
+        if rest:
+            print("\n".join(rest))
+    names = _demangle(list(resources))
+    import json
+
+    with open(RESOURCES, "w") as f:
+        json.dump({names[k].replace("(anonymous namespace)::", "").split("(")[0]: v for k, v in resources.items()}, f, indent=1, sort_keys=True)
     link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(link))

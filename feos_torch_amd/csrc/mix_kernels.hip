@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_mix_class_scatter(const double* __restr
 }
 
 template <bool DEW>
-__global__ __launch_bounds__(64) void k_mix_bubble_dew_queue(const double* __restrict__ params,
+__global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew_queue(const double* __restrict__ params,
                                                              const double* __restrict__ kij,
                                                              const double* __restrict__ temp,
                                                              const double* __restrict__ z,

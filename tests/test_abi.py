@@ -81,3 +81,24 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in src and "liboracle" not in src and "from oracle" not in src, f
+
+
+def test_kernel_stack_frames_and_occupancy(hip_lib):
+    """Compiler report of the last build (feos_torch_amd/build/resources.json).  Large per-lane stack frames make the
+    runtime throttle the resident waves (the mixture Jacobian ran at 21 ms instead of 10 ms per 1e6 rows with a
+    2.5-4 KB frame), so every kernel is held below 2.25 KB; the headline kernel must keep its
+    three waves per SIMD and use no stack at all."""
+    import json
+
+    from feos_torch_amd import build
+
+    with open(build.RESOURCES) as f:
+        res = json.load(f)
+    assert len(res) >= 20
+    for name, r in res.items():
+        assert r["scratch"] <= 2304, (name, r)
+    lite = [r for name, r in res.items() if "k_pure_vle<true>" in name]
+    assert len(lite) == 1 and lite[0]["scratch"] == 0 and lite[0]["occupancy"] >= 3, lite
+    for name, r in res.items():
+        if "k_pure_vle" in name or "k_pure_liquid_density" in name or "k_pure_derivatives" in name:
+            assert r["scratch"] == 0, (name, r)
