@@ -44,6 +44,21 @@ def test_pure_vapor_pressure_1e6(amd, oracle):
     assert int(r["status"].sum()) <= int(st.sum())  # the GPU path solves every row the oracle solves here
 
 
+def test_pure_liquid_densities_1e6(amd, oracle):
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch, pure_pressures
+
+    n = 1_000_000
+    P, T = pure_batch(n, seed=80)
+    pr = pure_pressures(n, seed=81)
+    r = native.pure_liquid_density(_d(P), _d(T), _d(pr))
+    want, st = oracle.pure_liquid_density(P, T, pr, prec=1)
+    _check(r["rho"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 100)
+    r = native.pure_vle(_d(P), _d(T), want_p=False, want_rho_eq=True, want_rho_vl=False)
+    want, st = oracle.pure_equilibrium_liquid_density(P, T, prec=1)
+    _check(r["rho_eq"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 100)
+
+
 @pytest.mark.parametrize("dew", [False, True])
 def test_mix_bubble_dew_1e5(amd, oracle, dew):
     from feos_torch_amd import native
