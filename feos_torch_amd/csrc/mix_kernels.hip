@@ -63,6 +63,9 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
 #ifndef PCS_MIX_QUEUE
 #define PCS_MIX_QUEUE 1  // 1: class-ordered work queue with persistent waves, 0: fast pass + retry pass
 #endif
+#ifndef PCS_REFILL_MIN
+#define PCS_REFILL_MIN 8  // lanes that must be idle before the wave refills (A/B dew 1e6 rows: 1: 7.9 ms, 4: 7.7, 8: 7.5, 16: 7.8)
+#endif
 #ifndef PCS_QUEUE_WAVES_PER_SIMD
 #define PCS_QUEUE_WAVES_PER_SIMD 1
 #endif
@@ -293,6 +296,9 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
     for (;;) {
         // hand rows to the lanes that have none
         unsigned long long need = __ballot(L.done());
+#if PCS_REFILL_MIN > 1
+        if (__popcll(need) < PCS_REFILL_MIN) need = 0ull;  // wait until a few lanes are free: the refill code runs for the whole wave
+#endif
         while (need != 0ull && !(drained && next >= end)) {
             if (next >= end) {
                 int head = 0;
