@@ -94,10 +94,11 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
     m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
     m.c.stride = GBLOCK;
     const int64_t first = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
-    const int64_t total = RETRY ? (int64_t)retry[0] : n;
+    const int64_t total = RETRY ? min((int64_t)max(retry[0], 0), n) : n;  // count and entries bounded by n: a foreign list must not fault
     const int64_t stride = RETRY ? (int64_t)gridDim.x * GBLOCK : total;  // fast pass: one row per lane
     for (int64_t k = first; k < total; k += stride) {
         const int64_t i = RETRY ? (int64_t)retry[1 + k] : k;
+        if (RETRY && (i < 0 || i >= n)) continue;
         const double T = temp[i];
         gc_coef<double>(m.c, rows + (size_t)i * GC_ROW_BYTES, tb, phi[2 * i], phi[2 * i + 1], T);
         MixResult r;

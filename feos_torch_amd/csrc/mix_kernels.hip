@@ -189,10 +189,11 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
                                                              const double* __restrict__ p_init,
                                                              double* __restrict__ p_out, double* __restrict__ rho4,
                                                              uint8_t* __restrict__ status, int32_t* __restrict__ iters,
-                                                             const int32_t* __restrict__ retry) {
-    const int count = retry[0];
+                                                             const int32_t* __restrict__ retry, int64_t n) {
+    const int count = (int)min((int64_t)max(retry[0], 0), n);  // count and entries bounded by n: a foreign list must not fault
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const int64_t i = retry[1 + k];
+        if (i < 0 || i >= n) continue;
         double par[16], k0, k1;
         load_mix_row(params, kij, i, par, k0, k1);
         const double T = temp[i];
@@ -467,13 +468,13 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
                            rho4, status, iters, retry);
         if (retry)
             hipLaunchKernelGGL(k_mix_bubble_dew_retry<true>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
-                               p_out, rho4, status, iters, (const int32_t*)retry);
+                               p_out, rho4, status, iters, (const int32_t*)retry, n);
     } else {
         hipLaunchKernelGGL(k_mix_bubble_dew<false>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
                            rho4, status, iters, retry);
         if (retry)
             hipLaunchKernelGGL(k_mix_bubble_dew_retry<false>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
-                               p_out, rho4, status, iters, (const int32_t*)retry);
+                               p_out, rho4, status, iters, (const int32_t*)retry, n);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_mix_bubble_dew launch", e);

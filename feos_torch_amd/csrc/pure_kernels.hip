@@ -20,7 +20,7 @@
 // stage 2 (k_pure_vle_robust) lives in pure_robust.hip, compiled with strict IEEE semantics
 namespace pcs_abi {
 int launch_pure_vle_retry(const double* params, const double* temp, double* p_sat, double* rho_eq, double* rho_vl,
-                          uint8_t* status, int32_t* iters, const int32_t* retry, hipStream_t s);
+                          uint8_t* status, int32_t* iters, const int32_t* retry, int64_t n, hipStream_t s);
 }
 #define launch_vle_retry pcs_abi::launch_pure_vle_retry
 
@@ -171,12 +171,15 @@ __global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restri
                                                           double* __restrict__ p_sat, double* __restrict__ rho_eq,
                                                           double* __restrict__ rho_vl,
                                                           uint8_t* __restrict__ status, int32_t* __restrict__ iters,
-                                                          int32_t* __restrict__ retry) {
-    const int count = retry[0];
+                                                          int32_t* __restrict__ retry, int64_t n) {
+    // count and entries are bounded by n: a list that was not produced by the main kernel of THIS launch (stale or
+    // uninitialised workspace handed to pcs_pure_vle_retry, a runtime that reorders the launches) must not fault
+    const int count = (int)min((int64_t)max(retry[0], 0), n);
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const uint32_t entry = (uint32_t)retry[1 + k];
         if (!(entry & 0x80000000u)) continue;
         const int64_t i = (int64_t)(entry & 0x7fffffffu);
+        if (i >= n) continue;
         double par[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) par[j] = params[8 * i + j];
@@ -311,7 +314,7 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
         hipLaunchKernelGGL(k_pure_vle<false>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                            iters, retry);
     hipLaunchKernelGGL(k_pure_vle_fallback, dim3(FALLBACK_GRID), dim3(64), 0, s, params, temp, p_sat, rho_eq, rho_vl, status,
-                       iters, retry);
+                       iters, retry, n);
     e = hipGetLastError();
     if (e != hipSuccess) return fail("k_pure_vle launch", e);
     return 0;
@@ -337,7 +340,7 @@ int pcs_pure_vle(const double* params, const double* temp, int64_t n, double* p_
     if (n == 0) return 0;
     int32_t* retry = static_cast<int32_t*>(workspace);
     if (int e = launch_vle_fast(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, as_stream(stream))) return e;
-    return launch_vle_retry(params, temp, p_sat, rho_eq, rho_vl, status, iters, retry, as_stream(stream));
+    return launch_vle_retry(params, temp, p_sat, rho_eq, rho_vl, status, iters, retry, n, as_stream(stream));
 }
 
 int pcs_pure_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
@@ -355,7 +358,7 @@ int pcs_pure_vle_retry(const double* params, const double* temp, int64_t n, doub
     if (int e = vle_args_ok(params, temp, n, status, workspace)) return e;
     if (n == 0) return 0;
     return launch_vle_retry(params, temp, p_sat, rho_eq, rho_vl, status, iters,
-                            static_cast<const int32_t*>(workspace), as_stream(stream));
+                            static_cast<const int32_t*>(workspace), n, as_stream(stream));
 }
 
 int pcs_pure_liquid_density(const double* params, const double* temp, const double* pressure, int64_t n,

@@ -20,12 +20,13 @@ __global__ __launch_bounds__(64) void k_pure_vle_robust(const double* __restrict
                                                         double* __restrict__ p_sat, double* __restrict__ rho_eq,
                                                         double* __restrict__ rho_vl, uint8_t* __restrict__ status,
                                                         int32_t* __restrict__ iters,
-                                                        const int32_t* __restrict__ retry) {
-    const int count = retry[0];
+                                                        const int32_t* __restrict__ retry, int64_t n) {
+    const int count = (int)min((int64_t)max(retry[0], 0), n);  // bounded by n, as the entries below (see k_pure_vle_fallback)
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const uint32_t entry = (uint32_t)retry[1 + k];
         if (entry & 0x80000000u) continue;  // solved by k_pure_vle_fallback (pure_kernels.hip)
         const int64_t i = (int64_t)entry;
+        if (i >= n) continue;
         double par[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) par[j] = params[8 * i + j];
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(64) void k_pure_vle_robust(const double* __restrict
 namespace pcs_abi {
 
 int launch_pure_vle_retry(const double* params, const double* temp, double* p_sat, double* rho_eq, double* rho_vl,
-                          uint8_t* status, int32_t* iters, const int32_t* retry, hipStream_t s) {
+                          uint8_t* status, int32_t* iters, const int32_t* retry, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_pure_vle_robust, dim3(RETRY_GRID), dim3(64), 0, s, params, temp, p_sat, rho_eq, rho_vl, status,
-                       iters, retry);
+                       iters, retry, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_pure_vle_robust launch", e);
     return 0;

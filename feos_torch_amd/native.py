@@ -161,7 +161,7 @@ class PureVlePlan:
     """Pre-allocated launch plan for repeated pure-VLE solves on a fixed number of rows: all
     outputs and the retry workspace are allocated once; ``run`` only enqueues kernels on the
     current HIP stream (no allocation, no host synchronisation), so steps can be timed with
-    HIP events or captured into a hipGraph."""
+    HIP events."""
 
     def __init__(self, n, device, want_rho_eq=False, want_rho_vl=False):
         self.n = int(n)

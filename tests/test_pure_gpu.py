@@ -367,3 +367,28 @@ def test_ffi_mirror_layout(amd, oracle):
     assert rho1.ndim == 1 and st1.shape == (3,)
     with pytest.raises(TypeError):
         amd.PcSaft.vapor_pressure(par.astype(np.float32), T)
+
+
+def test_retry_pass_survives_a_foreign_work_list(amd):
+    """pcs_pure_vle_retry consumes a work list from the caller's workspace.  A stale or uninitialised one (count and
+    entries arbitrary) must neither fault nor touch rows outside [0, n): count and entries are bounded by n on the
+    device.  Rows that do get re-solved end with the same result."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch
+
+    n = 20_000
+    P, T = pure_batch(n, seed=503)
+    dev = torch.device("cuda:0")
+    par, tem = torch.from_numpy(P).to(dev), torch.from_numpy(T).to(dev)
+    plan = native.PureVlePlan(n, dev, want_rho_vl=True)
+    plan.run(par, tem)
+    torch.cuda.synchronize()
+    ref_p, ref_s = plan.p_sat.clone(), plan.status.clone()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    junk = torch.randint(-2**31, 2**31 - 1, (plan.ws.numel(),), dtype=torch.int64, generator=g).to(torch.int32)
+    junk[1:2001] = torch.randint(0, n, (2000,), generator=g).to(torch.int32)  # some valid rows: re-solved by the robust pass
+    plan.ws.copy_(junk)
+    plan.run_retry(par, tem)
+    torch.cuda.synchronize()
+    assert torch.equal(plan.status, ref_s)
+    assert torch.allclose(plan.p_sat, ref_p, rtol=1e-9, atol=0.0)
