@@ -255,10 +255,17 @@ struct BdLane {
             if (!is_finite_bits(mx)) { stage = S_DONE; return; }
             if (mx < NEWTON_PROGRESS * err_best) { err_best = mx; it_best = it; }
             else if (it - it_best >= (DEW ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE)) { stage = S_DONE; return; }
-            const double scale = mx > 1.0 ? 1.0 / mx : 1.0;
+            // at most a factor e per iteration -- except for a trace component of the incipient phase (mole fraction below
+            // NEWTON_TRACE): its chemical potential is linear in ln rho_i there (ideal dilution), so the Newton step lands on
+            // the solution however long it is and limiting it only makes the iteration march (rows with p ~ 1e-10 Pa and
+            // x_i ~ 1e-30 needed 35 ... 90 iterations of unit steps, the longer ones ran into the cap)
+            const double rtot = ri0 + ri1;
+            const bool tr0 = ri0 < NEWTON_TRACE * rtot, tr1 = ri1 < NEWTON_TRACE * rtot;
+            const double mxl = fmax(fabs(du[0]), fmax(tr0 ? 0.0 : fabs(du[1]), tr1 ? 0.0 : fabs(du[2])));
+            const double scale = mxl > 1.0 ? 1.0 / mxl : 1.0;
             rs *= exp(scale * du[0]);
-            ri0 *= exp(scale * du[1]);
-            ri1 *= exp(scale * du[2]);
+            ri0 *= exp(tr0 ? fmin(fmax(du[1], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[1]);
+            ri1 *= exp(tr1 ? fmin(fmax(du[2], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[2]);
             out.iters = it + 1;
             const bool stagnated = it >= 3 && mx < 1e-7 && mx >= 0.25 * err_prev;
             err_prev = mx;

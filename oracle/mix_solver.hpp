@@ -69,6 +69,7 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
 constexpr double LIQ_ROOT_TOL = 1e-3;  // as csrc/mix_solver.hpp
 constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
 constexpr double NEWTON_PROGRESS = 0.9;
+constexpr double NEWTON_TRACE = 1e-4, NEWTON_TRACE_MAX = 100.0;
 constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point successive substitution hands over to Newton
 template <class F, class Model>
 bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out, F rho_start = F(0)) {
@@ -296,10 +297,22 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         static const double np_factor = getenv("ORC_NP_FACTOR") ? atof(getenv("ORC_NP_FACTOR")) : NEWTON_PROGRESS;
         if (mx < F(np_factor) * err_best) { err_best = mx; it_best = it; }
         else if (it - it_best >= no_progress) return false;
-        F scale = mx > F(1) ? F(1) / mx : F(1);  // at most a factor e per iteration
+        // at most a factor e per iteration -- except for a trace component of the incipient phase (mole fraction
+        // below NEWTON_TRACE): its chemical potential is linear in ln rho_i there (ideal dilution), the Newton step
+        // lands on the solution however long it is, and limiting it would only make the iteration march
+        static const bool trace_rule = getenv("ORC_NO_TRACE") == nullptr;
+        F rtot = ri[0] + ri[1];
+        bool tr0 = trace_rule && ri[0] < F(NEWTON_TRACE) * rtot, tr1 = trace_rule && ri[1] < F(NEWTON_TRACE) * rtot;
+        F mxl = du[0] < 0 ? -du[0] : du[0];
+        if (!tr0) { F a = du[1] < 0 ? -du[1] : du[1]; if (a > mxl) mxl = a; }
+        if (!tr1) { F a = du[2] < 0 ? -du[2] : du[2]; if (a > mxl) mxl = a; }
+        F scale = mxl > F(1) ? F(1) / mxl : F(1);
+        F s0 = scale * du[1], s1 = scale * du[2];
+        if (tr0) s0 = du[1] > F(NEWTON_TRACE_MAX) ? F(NEWTON_TRACE_MAX) : (du[1] < F(-NEWTON_TRACE_MAX) ? F(-NEWTON_TRACE_MAX) : du[1]);
+        if (tr1) s1 = du[2] > F(NEWTON_TRACE_MAX) ? F(NEWTON_TRACE_MAX) : (du[2] < F(-NEWTON_TRACE_MAX) ? F(-NEWTON_TRACE_MAX) : du[2]);
         rs = rs * exp(scale * du[0]);
-        ri[0] = ri[0] * exp(scale * du[1]);
-        ri[1] = ri[1] * exp(scale * du[2]);
+        ri[0] = ri[0] * exp(s0);
+        ri[1] = ri[1] * exp(s1);
         if (getenv("ORC_TRACE")) fprintf(stderr, "it %d mx %.3e du %.3e %.3e %.3e rs %.6e ri %.6e %.6e F %.3e %.3e %.3e\n", it, (double)mx, (double)du[0], (double)du[1], (double)du[2], (double)rs, (double)ri[0], (double)ri[1], (double)Fv[0], (double)Fv[1], (double)Fv[2]);
         info.iters = it + 1;
         bool stagnated = it >= 3 && mx < F(1e-7) && mx >= F(0.25) * err_prev;
