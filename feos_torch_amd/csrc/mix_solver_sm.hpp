@@ -267,6 +267,9 @@ struct BdLane {
             ri0 *= exp(tr0 ? fmin(fmax(du[1], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[1]);
             ri1 *= exp(tr1 ? fmin(fmax(du[2], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[2]);
             out.iters = it + 1;
+            // the iteration has collapsed onto the trivial solution (both phases identical): the Jacobian is singular there
+            // and the steps wander along its null direction until a cap stops them -> give the row up now
+            if (fabs(ri0 + ri1 - rs) <= 1e-6 * rs && fabs(ri0 - z0 * rs) <= 1e-6 * rs) { stage = S_DONE; return; }
             const bool stagnated = it >= 3 && mx < 1e-7 && mx >= 0.25 * err_prev;
             err_prev = mx;
             it++;

@@ -315,6 +315,10 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         ri[1] = ri[1] * exp(s1);
         if (getenv("ORC_TRACE")) fprintf(stderr, "it %d mx %.3e du %.3e %.3e %.3e rs %.6e ri %.6e %.6e F %.3e %.3e %.3e\n", it, (double)mx, (double)du[0], (double)du[1], (double)du[2], (double)rs, (double)ri[0], (double)ri[1], (double)Fv[0], (double)Fv[1], (double)Fv[2]);
         info.iters = it + 1;
+        {   // collapsed onto the trivial solution (both phases identical, singular Jacobian): give up (as csrc/mix_solver.hpp)
+            F dtot = ri[0] + ri[1] - rs, d0 = ri[0] - z[0] * rs;
+            if ((dtot < 0 ? -dtot : dtot) <= F(1e-6) * rs && (d0 < 0 ? -d0 : d0) <= F(1e-6) * rs) return false;
+        }
         bool stagnated = it >= 3 && mx < F(1e-7) && mx >= F(0.25) * err_prev;
         err_prev = mx;
         if (mx <= tol || stagnated) {
