@@ -24,7 +24,10 @@ using namespace pcs_abi;
 
 namespace {
 
-constexpr int GBLOCK = 128;
+#ifndef PCS_GBLOCK
+#define PCS_GBLOCK 128
+#endif
+constexpr int GBLOCK = PCS_GBLOCK;
 constexpr int GJBLOCK = 64;
 
 template <class P>
@@ -48,6 +51,9 @@ __device__ __forceinline__ GcTable stage_table(const double* __restrict__ table,
     return tb;
 }
 
+#ifndef PCS_GC_BUCKET
+#define PCS_GC_BUCKET 1
+#endif
 #ifndef PCS_GC_FAST_SS
 #define PCS_GC_FAST_SS 6  // A/B on the synthetic dew batch (scripts/dev/ab_gc.py): 12/12: 9.0 ms, 6/8: 7.9, 4/8: 8.4, 7/7: 8.6
 #endif
@@ -56,6 +62,35 @@ __device__ __forceinline__ GcTable stage_table(const double* __restrict__ table,
 #endif
 constexpr int GC_FAST_SS = PCS_GC_FAST_SS, GC_FAST_NEWTON = PCS_GC_FAST_NEWTON;  // fast-pass caps (mix_solver.hpp)
 constexpr int GC_RETRY_BLOCKS = 1024;
+
+// association class x polarity of a row (the evaluation's branches): key of the workgroup bucketing in the fast pass
+constexpr int GC_BINS = 8;
+__device__ __forceinline__ int gc_bucket(const unsigned char* __restrict__ row, const GcTable& tb) {
+    int associating = 0, self_assoc = 0, polar = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        double ka = 0.0, eab = 0.0, na = 0.0, nb = 0.0, mu2 = 0.0;
+#pragma unroll 1
+        for (int e = 0; e < GC_MAXE; e++) {
+            const int n = row[16 + i * GC_MAXE + e];
+            if (n == 0) continue;
+            const double* p = tb.seg + 8 * row[i * GC_MAXE + e];
+            mu2 += n * p[3] * p[3];
+            ka += n * p[4];
+            eab += n * p[5];
+            na += n * p[6];
+            nb += n * p[7];
+        }
+        associating += (ka * eab != 0.0);
+        self_assoc += (na * nb != 0.0);
+        polar |= (mu2 > 0.0);
+    }
+    int cls = 0;
+    if (associating == 1 && self_assoc == 1) cls = 1;
+    if (associating == 2 && self_assoc == 1) cls = 2;
+    if (associating == 2 && self_assoc == 2) cls = 3;
+    return 2 * cls + polar;
+}
 
 template <bool DEW>
 __device__ __forceinline__ void gc_store(int64_t i, int rc, const MixResult& r, double T, double* __restrict__ p_out,
@@ -93,7 +128,35 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
     m.c.bond_dab = bonds + threadIdx.x;
     m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
     m.c.stride = GBLOCK;
-    const int64_t first = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
+    int64_t first = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
+#if PCS_GC_BUCKET
+    if (!RETRY) {
+        // rows of the workgroup bucketed by class (LDS counting sort): lane t takes the row at sorted position t, so a
+        // wave mostly runs one set of branches of the evaluation
+        __shared__ int bins[GC_BINS + 1];
+        __shared__ int perm[GBLOCK];
+        const int t = threadIdx.x;
+        if (t <= GC_BINS) bins[t] = 0;
+        __syncthreads();
+        int key = GC_BINS;  // rows past n sort last
+        if (first < n) key = gc_bucket(rows + (size_t)first * GC_ROW_BYTES, tb);
+        atomicAdd(&bins[key], 1);
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0;
+#pragma unroll
+            for (int b = 0; b <= GC_BINS; b++) {
+                int c = bins[b];
+                bins[b] = acc;
+                acc += c;
+            }
+        }
+        __syncthreads();
+        perm[atomicAdd(&bins[key], 1)] = t;
+        __syncthreads();
+        first = (int64_t)blockIdx.x * GBLOCK + perm[t];
+    }
+#endif
     const int64_t total = RETRY ? min((int64_t)max(retry[0], 0), n) : n;  // count and entries bounded by n: a foreign list must not fault
     const int64_t stride = RETRY ? (int64_t)gridDim.x * GBLOCK : total;  // fast pass: one row per lane
     for (int64_t k = first; k < total; k += stride) {
