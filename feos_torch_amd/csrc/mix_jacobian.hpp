@@ -25,6 +25,29 @@ constexpr int MIX_DIRS = 19;  // 16 parameters (component 0 then 1), k_ij, eps_A
 #define PCS_MIX_CHUNK 2
 #endif
 constexpr int MIX_CHUNK = PCS_MIX_CHUNK;
+// Direction handled by slot j of a pass (-1: none).  With two directions per pass they are paired so that the
+// structurally-zero ones share passes (both dipole moments; the association parameters of one component; eps_AiBj alone):
+// a non-polar non-associating row runs 4 passes instead of 6, an associating one skips the eps_AiBj pass unless it is used.
+PCS_DEV int mix_direction(int pass, int j) {
+    if (MIX_CHUNK == 2) {
+        // (m0, s0) (e0, m1) (s1, e1) (kij, T) (mu0, mu1) (kap0, eab0) (na0, nb0) (kap1, eab1) (na1, nb1) (epsAB, -)
+        switch (2 * pass + j) {
+            case 0: return 0;   case 1: return 1;
+            case 2: return 2;   case 3: return 8;
+            case 4: return 9;   case 5: return 10;
+            case 6: return 16;  case 7: return 18;
+            case 8: return 3;   case 9: return 11;
+            case 10: return 4;  case 11: return 5;
+            case 12: return 6;  case 13: return 7;
+            case 14: return 12; case 15: return 13;
+            case 16: return 14; case 17: return 15;
+            case 18: return 17;
+            default: return -1;
+        }
+    }
+    const int d = pass * MIX_CHUNK + j;
+    return d < MIX_DIRS ? d : -1;
+}
 
 struct MixModelD {
     MixCoef<double> c;
@@ -40,20 +63,21 @@ __device__ __attribute__((noinline)) R mix_a_tangent(const MixCoef<G>& c, const 
 // coefficients with their parameter tangents for direction(s) d0 .. d0 + MIX_CHUNK - 1; out of line so that its
 // register spills live in its own stack frame (which the evaluation's frame then reuses) instead of the kernel's
 template <class G>
-__device__ __attribute__((noinline)) void mix_coef_tangent(MixCoef<G>& c, const double* __restrict__ par, double k0, double k1, double T, int d0) {
+__device__ __attribute__((noinline)) void mix_coef_tangent(MixCoef<G>& c, const double* __restrict__ par, double k0, double k1, double T, int pass) {
     G gp[16], gk0, gk1, gT;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         gp[k].v = par[k];
 #pragma unroll
-        for (int j = 0; j < MIX_CHUNK; j++) gp[k].e[j] = (d0 + j == k) ? 1.0 : 0.0;
+        for (int j = 0; j < MIX_CHUNK; j++) gp[k].e[j] = (mix_direction(pass, j) == k) ? 1.0 : 0.0;
     }
     gk0.v = k0; gk1.v = k1; gT.v = T;
 #pragma unroll
     for (int j = 0; j < MIX_CHUNK; j++) {
-        gk0.e[j] = (d0 + j == 16) ? 1.0 : 0.0;
-        gk1.e[j] = (d0 + j == 17) ? 1.0 : 0.0;
-        gT.e[j] = (d0 + j == 18) ? 1.0 : 0.0;
+        const int d = mix_direction(pass, j);
+        gk0.e[j] = (d == 16) ? 1.0 : 0.0;
+        gk1.e[j] = (d == 17) ? 1.0 : 0.0;
+        gT.e[j] = (d == 18) ? 1.0 : 0.0;
     }
     mix_coef<G>(c, gp, gk0, gk1, gT);
 }
@@ -117,14 +141,14 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
     const bool eab_used = m.c.acls == ASSOC_CROSS && k1 != 0.0;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; pass++) {
-        const int d0 = pass * MIX_CHUNK;
         {
             bool zero = true;  // every direction of this pass is structurally zero for this row
 #pragma unroll
             for (int j = 0; j < MIX_CHUNK; j++) {
-                const int d = d0 + j, kk = d & 7;
+                const int d = mix_direction(pass, j), kk = d & 7;
                 bool zj = true;
-                if (d < 16) zj = (kk == 3 && par[d] == 0.0) || (kk >= 4 && no_assoc);
+                if (d < 0) zj = true;
+                else if (d < 16) zj = (kk == 3 && par[d] == 0.0) || (kk >= 4 && no_assoc);
                 else if (d == 17) zj = !eab_used;
                 else if (d < MIX_DIRS) zj = false;
                 zero = zero && zj;
@@ -132,12 +156,12 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
             if (__ballot(!zero) == 0ull) {  // the whole wave skips the pass
 #pragma unroll
                 for (int j = 0; j < MIX_CHUNK; j++)
-                    if (d0 + j < MIX_DIRS) g[d0 + j] = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
+                    if (mix_direction(pass, j) >= 0) g[mix_direction(pass, j)] = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
                 continue;
             }
         }
         MixCoef<G> c;
-        mix_coef_tangent<G>(c, par, k0, k1, T, d0);
+        mix_coef_tangent<G>(c, par, k0, k1, T, pass);
         // both phases through ONE evaluation site (loop not unrolled, evaluation not inlined): the dual-number
         // evaluation is large, two inlined copies per pass cost ~5,000 spilled VGPRs
         double acc[MIX_CHUNK];
@@ -155,9 +179,10 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
         for (int j = 0; j < MIX_CHUNK; j++) {
             const double dp = acc[j];
             double val = dp * T * P_UNIT;
-            if (d0 + j == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
+            const int d = mix_direction(pass, j);
+            if (d == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
             if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
-            if (d0 + j < MIX_DIRS) g[d0 + j] = val;
+            if (d >= 0) g[d] = val;
         }
     }
 }

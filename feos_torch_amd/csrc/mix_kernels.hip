@@ -373,33 +373,41 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* 
                                                          const double* __restrict__ kij,
                                                          const double* __restrict__ temp,
                                                          const double* __restrict__ rho4, int64_t n,
-                                                         double* __restrict__ jac) {
-    // rows of the workgroup bucketed by class as in k_mix_bubble_dew: waves of non-associating rows skip the
-    // association directions altogether
+                                                         double* __restrict__ jac, const int32_t* __restrict__ order) {
+    // waves of non-associating / non-polar rows skip the structurally-zero directions altogether, so rows are taken
+    // in class order: from the batch-wide permutation of k_mix_class_* when the caller provides a workspace, else
+    // bucketed inside the workgroup as in k_mix_bubble_dew
     __shared__ int perm[MBLOCK];
     __shared__ int bins[MIX_BINS + 1];
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * MBLOCK;
-    if (t <= MIX_BINS) bins[t] = 0;
-    __syncthreads();
-    int key = MIX_BINS;
-    if (row0 + t < n) key = mix_bucket(params + 16 * (row0 + t));
-    atomicAdd(&bins[key], 1);
-    __syncthreads();
-    if (t == 0) {
-        int acc = 0;
+    int64_t i;
+    if (order) {
+        if (row0 + t >= n) return;
+        i = order[row0 + t];
+        if (i < 0 || i >= n) return;
+    } else {
+        if (t <= MIX_BINS) bins[t] = 0;
+        __syncthreads();
+        int key = MIX_BINS;
+        if (row0 + t < n) key = mix_bucket(params + 16 * (row0 + t));
+        atomicAdd(&bins[key], 1);
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0;
 #pragma unroll
-        for (int b = 0; b <= MIX_BINS; b++) {
-            int c = bins[b];
-            bins[b] = acc;
-            acc += c;
+            for (int b = 0; b <= MIX_BINS; b++) {
+                int c = bins[b];
+                bins[b] = acc;
+                acc += c;
+            }
         }
+        __syncthreads();
+        perm[atomicAdd(&bins[key], 1)] = t;
+        __syncthreads();
+        i = row0 + perm[t];
+        if (i >= n) return;
     }
-    __syncthreads();
-    perm[atomicAdd(&bins[key], 1)] = t;
-    __syncthreads();
-    const int64_t i = row0 + perm[t];
-    if (i >= n) return;
     double par[16], k0, k1;
     load_mix_row(params, kij, i, par, k0, k1);
     double4 r = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
@@ -496,14 +504,26 @@ int pcs_mix_derivatives(const double* params, const double* kij, const double* t
 }
 
 int pcs_mix_jacobian(int dew, const double* params, const double* kij, const double* temp, const double* rho4,
-                     int64_t n, double* jac, void* stream) {
+                     int64_t n, double* jac, void* workspace, void* stream) {
     g_err[0] = 0;
     if (int e = check_n(n)) return e;
     if (n == 0) return 0;
     if (!params || !kij || !temp || !rho4 || !jac) return fail_msg("pcs_mix_jacobian: null required pointer");
     const unsigned grid = (unsigned)((n + MBLOCK - 1) / MBLOCK);
-    hipLaunchKernelGGL(k_mix_jacobian, dim3(grid), dim3(MBLOCK), 0, as_stream(stream), dew, params, kij, temp, rho4, n,
-                       jac);
+    hipStream_t s = as_stream(stream);
+    const int32_t* order = nullptr;
+    if (workspace) {  // batch-wide class order (the permutation of the work-queue schedule)
+        int32_t* perm = static_cast<int32_t*>(workspace);
+        int32_t* ctrl = perm + n;
+        hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int32_t) * QCTRL_INTS, s);
+        if (e != hipSuccess) return fail("hipMemsetAsync", e);
+        const unsigned g256 = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);
+        hipLaunchKernelGGL(k_mix_class_scan, dim3(1), dim3(64), 0, s, ctrl);
+        hipLaunchKernelGGL(k_mix_class_scatter, dim3(g256), dim3(256), 0, s, params, n, ctrl, perm);
+        order = perm;
+    }
+    hipLaunchKernelGGL(k_mix_jacobian, dim3(grid), dim3(MBLOCK), 0, s, dew, params, kij, temp, rho4, n, jac, order);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_mix_jacobian launch", e);
     return 0;

@@ -281,8 +281,9 @@ def mix_jacobian(params, kij, temperature, rho4, dew):
     L = _lib.lib()
     with torch.cuda.device(device):
         jac = torch.empty((n, 19), dtype=_F64, device=device)
+        ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
         rc = L.pcs_mix_jacobian(int(bool(dew)), _lib.ptr(params), _lib.ptr(kij), _lib.ptr(temperature),
-                                _lib.ptr(rho4), n, _lib.ptr(jac), _lib.current_stream_ptr(device))
+                                _lib.ptr(rho4), n, _lib.ptr(jac), _lib.ptr(ws), _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_mix_jacobian")
     return jac
 

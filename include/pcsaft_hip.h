@@ -134,9 +134,11 @@ int pcs_mix_derivatives(const double* params, const double* kij, const double* t
  * Gradient of the bubble (dew = 0) / dew (dew = 1) pressure [Pa] at the converged densities rho4
  * (from pcs_mix_bubble_dew) — what torch reverse mode through feos_torch/pcsaft_mix.py:435-444 /
  * :459-468 yields.  jac [n,19] = d p / d (params[0,0..7], params[1,0..7], kij[0], kij[1], T).
+ * workspace: device scratch of pcs_workspace_bytes(n) or NULL.  With it the rows are processed in batch-wide class
+ * order (waves of non-polar / non-associating rows skip the structurally-zero directions); results are identical.
  */
 int pcs_mix_jacobian(int dew, const double* params, const double* kij, const double* temp, const double* rho4,
-                     int64_t n, double* jac, void* stream);
+                     int64_t n, double* jac, void* workspace, void* stream);
 
 /*
  * ---- heterosegmented gc-PC-SAFT (binary mixtures) -----------------------------------------

@@ -122,6 +122,28 @@ def test_jacobian_vs_oracle(amd, oracle):
         assert err.max() < 1e-4
 
 
+def test_jacobian_class_order_is_only_a_schedule(amd):
+    """pcs_mix_jacobian with a workspace takes the rows in batch-wide class order; without it they are bucketed inside
+    the workgroup.  Same arithmetic per row: identical results."""
+    from feos_torch_amd import _lib, native
+    from feos_torch_amd.synthetic import mix_batch
+
+    n = 30_000
+    P, K, T, X, PI = mix_batch(n, seed=41)
+    a = [_t(v).cuda() for v in (P, K, T, X, PI)]
+    r = native.mix_bubble_dew(*a, False)
+    rho4 = r["rho4"].clone()
+    rho4[r["status"]] = torch.tensor([1e-6, 1e-6, 5e-3, 5e-3], dtype=torch.float64, device="cuda")
+    with_ws = native.mix_jacobian(a[0], a[1], a[2], rho4, False)
+    plain = torch.empty_like(with_ws)
+    L = _lib.lib()
+    _lib.check(L.pcs_mix_jacobian(0, _lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(rho4), n, _lib.ptr(plain), None,
+                                  _lib.current_stream_ptr(plain.device)), "pcs_mix_jacobian")
+    torch.cuda.synchronize()
+    ok = ~r["status"]
+    assert torch.equal(with_ws[ok], plain[ok])
+
+
 @pytest.mark.parametrize("dew", [False, True])
 def test_phase_equilibrium_conditions_large_batch(amd, dew):
     """size-independent check at 1e6 rows (config 4): equal chemical potentials and pressures,
