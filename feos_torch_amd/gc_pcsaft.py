@@ -101,7 +101,7 @@ class _GcBubbleDew(torch.autograd.Function):
         ph = native._prep(phi, dev, (2,))
         T = native._prep(temperature, dev)
         r = native.gc_bubble_dew(table, model.S, model.rows, ph, T, native._prep(molefracs, dev),
-                                 native._prep(pressure, dev), dew)
+                                 native._prep(pressure, dev), dew, order=model._class_order(table))
         nans = r["status"]
         all_ok = not bool(nans.any())  # every row converged: slices instead of boolean gathers
         ok = slice(None) if all_ok else ~nans
@@ -184,6 +184,7 @@ class GcPcSaftMix:
             if np.any(cnt > 1):
                 raise Exception("Only up to one associating segment per component is allowed!")
         self.rows = torch.from_numpy(rows).to(self.device)
+        self._order = None  # class order of the rows, see _class_order
         idx = {s: i for i, s in enumerate(self.segment_identifier)}
         # symmetric k_ab matrix built exactly as the reference does (:60-63), keeps autograd history
         self.kab = torch.zeros((self.S, self.S), dtype=torch.float64)
@@ -217,12 +218,20 @@ class GcPcSaftMix:
         self.reduce(nans)
         return value, nans
 
+    def _class_order(self, table):
+        """Class order of the model's rows for the kernels' schedule (native.gc_class_order): computed on first use and
+        again after `reduce` — the rows are fixed in between."""
+        if self._order is None or self._order.shape[0] != self.rows.shape[0]:
+            self._order = native.gc_class_order(table, self.S, self.rows)
+        return self._order
+
     def reduce(self, nans):
         """Drop failed rows from the model (:514-528)."""
         if not bool(nans.any()):
             return
         self.rows = self.rows[~nans.to(self.rows.device)]
         self.phi = self.phi[~nans.to(self.phi.device)]
+        self._order = None
 
 
 class GcPcSaft:
@@ -244,6 +253,7 @@ class GcPcSaft:
             kab[idx[s2], idx[s1]] = float(k)
         self.table = build_table(self.seg.to(self.device), kab.to(self.device))
         self.phi = torch.as_tensor(np.asarray(phi, dtype=np.float64))
+        self._order = None
 
     @classmethod
     def _from_model(cls, model):
@@ -251,12 +261,15 @@ class GcPcSaft:
         obj.S, obj.device, obj.seg, obj.rows = model.S, model.device, model.seg, model.rows
         obj.table = model._table()
         obj.phi = model.phi.detach()
+        obj._order = None
         return obj
 
     def _solve(self, temperature, molefracs, pressure, dew):
         t, x, p = (native._as_f64(v, 1) for v in (temperature, molefracs, pressure))
+        if self._order is None or self._order.shape[0] != self.rows.shape[0]:
+            self._order = native.gc_class_order(self.table, self.S, self.rows)
         r = native.gc_bubble_dew(self.table, self.S, self.rows, self.phi, torch.from_numpy(t), torch.from_numpy(x),
-                                 torch.from_numpy(p), dew)
+                                 torch.from_numpy(p), dew, order=self._order)
         status = r["status"].cpu().numpy()
         return r["rho4"].cpu().numpy()[~status], status
 

@@ -291,14 +291,43 @@ def mix_jacobian(params, kij, temperature, rho4, dew):
 # ------------------------------------------------------------------------------------------
 # heterosegmented gc-PC-SAFT
 # ------------------------------------------------------------------------------------------
-def gc_bubble_dew(table, S, rows, phi, temperature, molefracs, pressure, dew, want_iters=False):
-    """table [S*8+3*S*S] f64, rows [n,80] u8 (include/pcsaft_hip.h).  -> dict(p, rho4, status, iters)."""
+def gc_class_order(table, S, rows):
+    """Permutation (position -> row, int32 on the device) that sorts the rows of a gc model by model class — association
+    class x polarity, expensive classes first — for the `order` argument of gc_bubble_dew.  The rows of a model are
+    fixed, so this is computed once per model (and again after `reduce`)."""
+    n = rows.shape[0]
+    seg = table[: S * 8].view(S, 8)
+    ids = rows[:, 0:16].long()
+    cnt = rows[:, 16:32].to(_F64)
+    par = seg[ids]  # [n,16,8]
+
+    def per_molecule(v):
+        return (cnt * v).view(n, 2, 8).sum(dim=2)
+
+    ka, eab = per_molecule(par[:, :, 4]), per_molecule(par[:, :, 5])
+    na, nb = per_molecule(par[:, :, 6]), per_molecule(par[:, :, 7])
+    mu2 = per_molecule(par[:, :, 3] ** 2)
+    associating = ((ka * eab) != 0).sum(dim=1)
+    self_assoc = ((na * nb) != 0).sum(dim=1)
+    cls = torch.zeros(n, dtype=torch.int64, device=rows.device)
+    cls[(associating == 1) & (self_assoc == 1)] = 1
+    cls[(associating == 2) & (self_assoc == 1)] = 2
+    cls[(associating == 2) & (self_assoc == 2)] = 3
+    key = 2 * cls + (mu2 > 0).any(dim=1).long()
+    return torch.argsort(key, descending=True, stable=True).to(torch.int32)
+
+
+def gc_bubble_dew(table, S, rows, phi, temperature, molefracs, pressure, dew, want_iters=False, order=None):
+    """table [S*8+3*S*S] f64, rows [n,80] u8 (include/pcsaft_hip.h); order: optional class order of the rows
+    (gc_class_order).  -> dict(p, rho4, status, iters)."""
     device = table.device
     phi = _prep(phi, device, (2,))
     temperature = _prep(temperature, device)
     molefracs = _prep(molefracs, device)
     pressure = _prep(pressure, device)
     n = temperature.shape[0]
+    if order is not None and (order.dtype != torch.int32 or order.shape != (n,) or order.device != device or not order.is_contiguous()):
+        raise ValueError("order must be a contiguous int32 tensor [n] on the device of the table")
     L = _lib.lib()
     with torch.cuda.device(device):
         p = torch.empty(n, dtype=_F64, device=device)
@@ -308,7 +337,7 @@ def gc_bubble_dew(table, S, rows, phi, temperature, molefracs, pressure, dew, wa
         ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
         rc = L.pcs_gc_bubble_dew(int(bool(dew)), _lib.ptr(table), int(S), _lib.ptr(rows), _lib.ptr(phi),
                                  _lib.ptr(temperature), _lib.ptr(molefracs), _lib.ptr(pressure), n, _lib.ptr(p),
-                                 _lib.ptr(rho4), _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws),
+                                 _lib.ptr(rho4), _lib.ptr(status), _lib.ptr(iters), _lib.ptr(order), _lib.ptr(ws),
                                  _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_gc_bubble_dew")
     return {"p": p, "rho4": rho4, "status": status.bool(), "iters": iters}

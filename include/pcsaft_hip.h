@@ -155,11 +155,15 @@ int pcs_mix_jacobian(int dew, const double* params, const double* kij, const dou
  *   phi    [n,2]         in   src/gc_pcsaft.rs:30, feos_torch/gc_pcsaft.py:182-185
  *   temp, z, p_init [n]  in   as for pcs_mix_bubble_dew
  *   outputs, workspace        as for pcs_mix_bubble_dew
+ *   order  [n] int32     in   optional (NULL: rows are bucketed by class inside each workgroup): a permutation of the rows,
+ *                             position -> row, normally sorted by model class (association class x polarity) so that a
+ *                             wavefront runs one set of branches.  The rows of a model are fixed, so the caller computes
+ *                             it once.  Only the schedule changes: results are identical.
  */
 int64_t pcs_gc_table_doubles(int S);
 int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
                       const double* z, const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status,
-                      int32_t* iters, void* workspace, void* stream);
+                      int32_t* iters, const int32_t* order, void* workspace, void* stream);
 
 /* GcPcSaftMix.derivatives (feos_torch/gc_pcsaft.py:443-468): a, p, mu [n,2], v [n,2] at rho [n,2]. */
 int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,

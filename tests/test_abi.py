@@ -52,6 +52,7 @@ def test_argument_validation_without_gpu(hip_lib):
         "pcs_mix_bubble_dew": lambda n, req: L.pcs_mix_bubble_dew(0, req, req, req, req, req, n, nul, nul, req, nul, nul, nul),
         "pcs_mix_derivatives": lambda n, req: L.pcs_mix_derivatives(req, req, req, req, n, nul, nul, nul, nul, nul),
         "pcs_mix_jacobian": lambda n, req: L.pcs_mix_jacobian(0, req, req, req, req, n, req, nul, nul),
+        "pcs_gc_bubble_dew": lambda n, req: L.pcs_gc_bubble_dew(0, req, 4, req, req, req, req, req, n, nul, nul, req, nul, nul, nul, nul),
     }
     for name, call in calls.items():
         assert call(0, nul) == 0, name  # empty batch: nothing to check, nothing to do

@@ -86,7 +86,12 @@ def test_gc_bubble_dew_25k(amd, oracle, dew):
         kab[ident.index(s1), ident.index(s2)] = k
         kab[ident.index(s2), ident.index(s1)] = k
     tab = build_table(seg.cuda(), kab.cuda())
-    r = native.gc_bubble_dew(tab, len(ident), rows, _d(b["phi"]), _d(b["T"]), _d(b["x"]), _d(b["p_init"]), dew)
+    order = native.gc_class_order(tab, len(ident), rows)
+    assert sorted(order.tolist()) == list(range(rows.shape[0]))
+    r = native.gc_bubble_dew(tab, len(ident), rows, _d(b["phi"]), _d(b["T"]), _d(b["x"]), _d(b["p_init"]), dew, order=order)
+    # the class order is only a schedule: bucketing inside the workgroup (order=None) gives the same bits
+    r0 = native.gc_bubble_dew(tab, len(ident), rows, _d(b["phi"]), _d(b["T"]), _d(b["x"]), _d(b["p_init"]), dew)
+    assert torch.equal(r["status"], r0["status"]) and torch.equal(r["p"], r0["p"]) and torch.equal(r["rho4"], r0["rho4"])
     enc = oracle.gc_encode(table, b["segment_lists"], b["bond_lists"], b["kab_list"])
     want, _, st = oracle.gc_bubble_dew(enc, b["phi"], b["T"], b["x"], b["p_init"], dew, prec=1)
     _check(r["p"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 10)
