@@ -231,15 +231,20 @@ __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* 
                                                          const double* __restrict__ phi,
                                                          const double* __restrict__ temp,
                                                          const double* __restrict__ rho4, int64_t n,
-                                                         double* __restrict__ jac, double* __restrict__ agg) {
+                                                         double* __restrict__ jac, double* __restrict__ agg,
+                                                         const int32_t* __restrict__ order) {
     typedef DN<double, GC_CHUNK> G;
     typedef T1<G> R;
     extern __shared__ double lds[];
     GcTable tb = stage_table(table, S, lds);
     double* bonds = lds + gc_table_doubles(S);                       // double model: [2*MAXE dab][2*MAXE cnt] x block
     G* gbonds = reinterpret_cast<G*>(bonds + 4 * GC_MAXE * GJBLOCK);  // dual model dab
-    const int64_t i = (int64_t)blockIdx.x * GJBLOCK + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * GJBLOCK + threadIdx.x;
     if (i >= n) return;
+    if (order) {  // class order of the rows (see pcs_gc_bubble_dew)
+        i = order[i];
+        if (i < 0 || i >= n) return;
+    }
     const unsigned char* row = rows + (size_t)i * GC_ROW_BYTES;
     const double T = temp[i], ph0 = phi[2 * i], ph1 = phi[2 * i + 1];
     const double4 r4 = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
@@ -404,7 +409,7 @@ int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const do
 }
 
 int pcs_gc_jacobian(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
-                    const double* rho4, int64_t n, double* jac, double* agg, void* stream) {
+                    const double* rho4, int64_t n, double* jac, double* agg, const int32_t* order, void* stream) {
     g_err[0] = 0;
     if (int e = gc_check(S, n)) return e;
     if (n == 0) return 0;
@@ -413,7 +418,7 @@ int pcs_gc_jacobian(int dew, const double* table, int S, const uint8_t* rows, co
     // double model: 4*MAXE doubles per thread; dual model dab: 2*MAXE * (1 + GC_CHUNK) doubles per thread
     const size_t lds = gc_lds_bytes(S, GJBLOCK, 4 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK));
     hipLaunchKernelGGL(k_gc_jacobian, dim3(grid), dim3(GJBLOCK), lds, as_stream(stream), dew, table, S, rows, phi, temp,
-                       rho4, n, jac, agg);
+                       rho4, n, jac, agg, order);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_gc_jacobian launch", e);
     return 0;

@@ -109,7 +109,9 @@ class _GcBubbleDew(torch.autograd.Function):
         needs = [ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]]
         if any(needs):
             rows_ok = model.rows[ok]
-            jac, agg = native.gc_jacobian(table, model.S, rows_ok, ph[ok], T[ok], r["rho4"][ok], dew)
+            # the class order belongs to the uncompacted rows: used when every row converged
+            jac, agg = native.gc_jacobian(table, model.S, rows_ok, ph[ok], T[ok], r["rho4"][ok], dew,
+                                          order=model._class_order(table) if all_ok else None)
             ctx.save_for_backward(jac, agg, nans.new_empty(0) if all_ok else ok, rows_ok, ph[ok], T[ok], table)
         ctx.all_ok = all_ok
         ctx.needs = needs

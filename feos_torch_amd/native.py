@@ -362,8 +362,8 @@ def gc_derivatives(table, S, rows, phi, temperature, density):
     return a, p, mu, v
 
 
-def gc_jacobian(table, S, rows, phi, temperature, rho4, dew):
-    """-> jac [n,7] = dp/d(A00, A01, A11, B00, B01, B11, T), agg [n,6]."""
+def gc_jacobian(table, S, rows, phi, temperature, rho4, dew, order=None):
+    """-> jac [n,7] = dp/d(A00, A01, A11, B00, B01, B11, T), agg [n,6].  order: optional class order (gc_class_order)."""
     device = table.device
     phi = _prep(phi, device, (2,))
     temperature = _prep(temperature, device)
@@ -375,6 +375,7 @@ def gc_jacobian(table, S, rows, phi, temperature, rho4, dew):
         agg = torch.empty((n, 6), dtype=_F64, device=device)
         rc = L.pcs_gc_jacobian(int(bool(dew)), _lib.ptr(table), int(S), _lib.ptr(rows), _lib.ptr(phi),
                                _lib.ptr(temperature), _lib.ptr(rho4), n, _lib.ptr(jac), _lib.ptr(agg),
+                               _lib.ptr(order) if order is not None and order.shape[0] == n else None,
                                _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_gc_jacobian")
     return jac, agg

@@ -174,10 +174,11 @@ int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const do
  *   jac [n,7] = d p / d (A00, A01, A11, B00, B01, B11, T), the dispersion aggregates
  *               rho1mix = A00 r0^2 + A01 r0 r1 + A11 r1^2, rho2mix likewise with B
  *               (feos_torch/gc_pcsaft.py:177-194) — k_ab and phi enter the model only through them;
- *   agg [n,6] = the aggregate values (optional).
+ *   agg [n,6] = the aggregate values (optional);
+ *   order [n]   = optional class order of the rows as for pcs_gc_bubble_dew (schedule only).
  */
 int pcs_gc_jacobian(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
-                    const double* rho4, int64_t n, double* jac, double* agg, void* stream);
+                    const double* rho4, int64_t n, double* jac, double* agg, const int32_t* order, void* stream);
 
 #ifdef __cplusplus
 }

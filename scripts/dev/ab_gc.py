@@ -25,12 +25,13 @@ def t(fn, reps=4):
     return np.median(ts), r
 for nm in sys.argv[1:]:
     _lib.LIB_PATH = os.path.abspath(f"scratch/ab/lib_{nm}.so"); _lib._lib = None
+    order = native.gc_class_order(tab, len(ident), rows)
     out = [nm]
     for dew in (False, True):
-        ms, r = t(lambda: native.gc_bubble_dew(tab, len(ident), rows, phi, T, x, p0, dew))
+        ms, r = t(lambda: native.gc_bubble_dew(tab, len(ident), rows, phi, T, x, p0, dew, order=order))
         out.append(f"{'dew' if dew else 'bubble'} {ms:.2f} ms fails {int(r['status'].sum())}")
         if not dew:
             rho4 = r["rho4"].clone(); rho4[r["status"]] = torch.tensor([1e-6, 1e-6, 5e-3, 5e-3], dtype=torch.float64, device="cuda")
-            ms, jj = t(lambda: native.gc_jacobian(tab, len(ident), rows, phi, T, rho4, False)); j = jj[0] if isinstance(jj, (tuple, list)) else jj
-            out.append(f"jacobian {ms:.2f} ms sum {float(j[~r['status']].abs().sum()):.12e}")
+            ms0, _ = t(lambda: native.gc_jacobian(tab, len(ident), rows, phi, T, rho4, False)); ms, jj = t(lambda: native.gc_jacobian(tab, len(ident), rows, phi, T, rho4, False, order=order)); j = jj[0] if isinstance(jj, (tuple, list)) else jj
+            out.append(f"jacobian {ms0:.2f} -> ordered {ms:.2f} ms sum {float(j[~r['status']].abs().sum()):.12e}")
     print("  ".join(out))

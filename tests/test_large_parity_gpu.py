@@ -92,6 +92,11 @@ def test_gc_bubble_dew_25k(amd, oracle, dew):
     # the class order is only a schedule: bucketing inside the workgroup (order=None) gives the same bits
     r0 = native.gc_bubble_dew(tab, len(ident), rows, _d(b["phi"]), _d(b["T"]), _d(b["x"]), _d(b["p_init"]), dew)
     assert torch.equal(r["status"], r0["status"]) and torch.equal(r["p"], r0["p"]) and torch.equal(r["rho4"], r0["rho4"])
+    ok = ~r["status"]
+    rho4 = torch.where(ok[:, None], r["rho4"], torch.tensor([1e-6, 1e-6, 5e-3, 5e-3], dtype=torch.float64, device="cuda"))
+    j1, a1 = native.gc_jacobian(tab, len(ident), rows, _d(b["phi"]), _d(b["T"]), rho4, dew, order=order)
+    j0, a0 = native.gc_jacobian(tab, len(ident), rows, _d(b["phi"]), _d(b["T"]), rho4, dew)
+    assert torch.equal(j1, j0) and torch.equal(a1, a0)
     enc = oracle.gc_encode(table, b["segment_lists"], b["bond_lists"], b["kab_list"])
     want, _, st = oracle.gc_bubble_dew(enc, b["phi"], b["T"], b["x"], b["p_init"], dew, prec=1)
     _check(r["p"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 10)
