@@ -28,7 +28,7 @@ def counters(sub):
     files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     if not files:
         return acc, meta
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         k = r["Kernel_Name"]
         acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         meta[k] = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
@@ -41,7 +41,7 @@ def short(k):
     return k.split("(")[0][:60]
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)  # newest: gpurun merges runs
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 lines = [f"# rocprofv3 summary `{tag}`", "",
