@@ -314,6 +314,11 @@ def gc_class_order(table, S, rows):
     cls[(associating == 2) & (self_assoc == 1)] = 2
     cls[(associating == 2) & (self_assoc == 2)] = 3
     key = 2 * cls + (mu2 > 0).any(dim=1).long()
+    # inside a class: by the number of bond-type and segment-type entries (the trip counts of the per-row loops);
+    # measured with host-sorted rows, 1e6 rows: class only 2.09 / 5.65 ms (bubble / dew), with these 2.01 / 5.33 ms
+    bonds = (rows[:, 64:80] > 0).view(n, 2, 8).sum(dim=2).max(dim=1).values.long()
+    segs = (rows[:, 16:32] > 0).sum(dim=1).long()
+    key = (key * 9 + bonds) * 17 + segs
     return torch.argsort(key, descending=True, stable=True).to(torch.int32)
 
 

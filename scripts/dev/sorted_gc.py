@@ -32,9 +32,13 @@ def t(fn, reps=4):
         e0.record(); r = fn(); e1.record(); torch.cuda.synchronize()
         if k: ts.append(e0.elapsed_time(e1))
     return np.median(ts)
-for name, order in (("seeded order", np.arange(n)), ("sorted by class", np.argsort(key, kind="stable"))):
+nb0 = (rows[:, 64:72] > 0).sum(axis=1); nb1 = (rows[:, 72:80] > 0).sum(axis=1)  # bond-type entries per molecule
+ns0 = (rows[:, 16:24] > 0).sum(axis=1); ns1 = (rows[:, 24:32] > 0).sum(axis=1)  # segment-type entries per molecule
+for name, order in (("seeded order", np.arange(n)), ("sorted by class", np.argsort(key, kind="stable")),
+                    ("class, bond entries", np.lexsort((nb0 + nb1, key))), ("class, max bonds, segs", np.lexsort((ns0 + ns1, np.maximum(nb0, nb1), key))),
+                    ("class, T", np.lexsort((b["T"], key)))):
     a = [d(v[order]) for v in (rows, b["phi"], b["T"], b["x"], b["p_init"])]
-    out = [name]
+    out = [f"{name:24s}"]
     for dew in (False, True):
         out.append(f"{'dew' if dew else 'bubble'} {t(lambda: native.gc_bubble_dew(tab, len(ident), a[0], a[1], a[2], a[3], a[4], dew)):.2f} ms")
     print("  ".join(out))
