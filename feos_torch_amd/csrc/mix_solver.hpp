@@ -237,11 +237,14 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
                 }
             }
             double rlc = rl + drho;
-            double w0 = z0 / (rlc * exp(e.g0 + (x0 * e.h00 + x1 * e.h01) * drho));
-            double w1 = z1 / (rlc * exp(e.g1 + (x0 * e.h01 + x1 * e.h11) * drho));
+            // w_i = z_i / (rho exp(G_i)) with the smaller exponent factored out: far from the solution G_i exceeds the range
+            // of exp (both weights 0, composition 0/0) although only their ratio and the pressure estimate are needed
+            double G0 = e.g0 + (x0 * e.h00 + x1 * e.h01) * drho, G1 = e.g1 + (x0 * e.h01 + x1 * e.h11) * drho;
+            double Gm = fmin(G0, G1);
+            double w0 = z0 * exp(Gm - G0), w1 = z1 * exp(Gm - G1);
             rl = rlc;
-            double sum = w0 + w1;
-            double n0 = w0 / sum, n1 = w1 / sum;
+            double sum = (w0 + w1) / (rlc * exp(Gm));
+            double n0 = w0 / (w0 + w1), n1 = w1 / (w0 + w1);
             double dx = fabs(n0 - x0);
             // The sweep is a scalar fixed-point map xi -> G(xi) in xi = ln(x_1/x_2); its plain iteration converges
             // linearly (slowly for strongly non-ideal liquids), so from the second sweep on the secant step on

@@ -173,11 +173,14 @@ struct BdLane {
             }
             resolved = false;
             const double rlc = rl + drho;
-            const double w0 = z0 / (rlc * exp(e.g0 + (x0 * e.h00 + x1 * e.h01) * drho));
-            const double w1 = z1 / (rlc * exp(e.g1 + (x0 * e.h01 + x1 * e.h11) * drho));
+            // w_i = z_i / (rho exp(G_i)) with the smaller exponent factored out: far from the solution G_i exceeds the range
+            // of exp (both weights 0, composition 0/0) although only their ratio and the pressure estimate are needed
+            const double G0 = e.g0 + (x0 * e.h00 + x1 * e.h01) * drho, G1 = e.g1 + (x0 * e.h01 + x1 * e.h11) * drho;
+            const double Gm = fmin(G0, G1);
+            const double w0 = z0 * exp(Gm - G0), w1 = z1 * exp(Gm - G1);
             rl = rlc;
-            const double sum = w0 + w1;
-            double n0 = w0 / sum, n1 = w1 / sum;
+            const double sum = (w0 + w1) / (rlc * exp(Gm));
+            double n0 = w0 / (w0 + w1), n1 = w1 / (w0 + w1);
             const double dx = fabs(n0 - x0);
             const double xi = log(x0 / x1);
             const double res = log(n0 / n1) - xi;

@@ -204,11 +204,15 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
                 if (attempt == 1) { if (!(dp > 0) || !(p == p)) return false; if (!(ad <= F(0.05) * rl)) drho = F(0); }
             }
             F rlc = rl + drho;
-            F w[2];
-            for (int i = 0; i < 2; i++) w[i] = z[i] / (rlc * exp(e.g[i] + (x[0] * e.h[i][0] + x[1] * e.h[i][1]) * drho));
+            // w_i = z_i / (rho exp(G_i)) with the smaller exponent factored out (as csrc/mix_solver.hpp): far from the
+            // solution G_i exceeds the range of exp although only the ratio of the weights and 1/sum are needed
+            F G[2], w[2];
+            for (int i = 0; i < 2; i++) G[i] = e.g[i] + (x[0] * e.h[i][0] + x[1] * e.h[i][1]) * drho;
+            F Gm = G[0] < G[1] ? G[0] : G[1];
+            for (int i = 0; i < 2; i++) w[i] = z[i] * exp(Gm - G[i]);
             rl = rlc;
-            F sum = w[0] + w[1];
-            F xn[2] = {w[0] / sum, w[1] / sum};
+            F sum = (w[0] + w[1]) / (rlc * exp(Gm));
+            F xn[2] = {w[0] / (w[0] + w[1]), w[1] / (w[0] + w[1])};
             F dx = xn[0] - x[0];
             if (dx < 0) dx = -dx;
             // The sweep is a scalar fixed-point map xi -> G(xi) in xi = ln(x_1/x_2); its plain iteration converges
