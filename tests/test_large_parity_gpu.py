@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCALE = int(os.environ.get("PCS_PARITY_SCALE", "1"))  # multiplies the mixture / gc batch sizes for a manual soak run
+SCALE = int(os.environ.get("PCS_PARITY_SCALE", "1"))  # multiplies the batch sizes for a manual soak run
 
 
 @pytest.fixture(scope="module")
@@ -41,10 +41,10 @@ def test_pure_vapor_pressure_1e6(amd, oracle):
     from feos_torch_amd import native
     from feos_torch_amd.synthetic import pure_batch
 
-    P, T = pure_batch(1_000_000, seed=77)
+    P, T = pure_batch(1_000_000 * SCALE, seed=77)
     r = native.pure_vle(_d(P), _d(T), want_rho_vl=False)  # the pressure-only kernel of the headline benchmark
     want, st = oracle.pure_vapor_pressure(P, T, prec=1)
-    _check(r["p_sat"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 100)
+    _check(r["p_sat"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 100 * SCALE)
     assert int(r["status"].sum()) <= int(st.sum())  # the GPU path solves every row the oracle solves here
 
 
@@ -52,15 +52,15 @@ def test_pure_liquid_densities_1e6(amd, oracle):
     from feos_torch_amd import native
     from feos_torch_amd.synthetic import pure_batch, pure_pressures
 
-    n = 1_000_000
+    n = 1_000_000 * SCALE
     P, T = pure_batch(n, seed=80)
     pr = pure_pressures(n, seed=81)
     r = native.pure_liquid_density(_d(P), _d(T), _d(pr))
     want, st = oracle.pure_liquid_density(P, T, pr, prec=1)
-    _check(r["rho"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 100)
+    _check(r["rho"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 100 * SCALE)
     r = native.pure_vle(_d(P), _d(T), want_p=False, want_rho_eq=True, want_rho_vl=False)
     want, st = oracle.pure_equilibrium_liquid_density(P, T, prec=1)
-    _check(r["rho_eq"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 100)
+    _check(r["rho_eq"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 100 * SCALE)
 
 
 @pytest.mark.parametrize("dew", [False, True])
