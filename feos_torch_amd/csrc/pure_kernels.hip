@@ -353,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_pure_jacobian(const double* __restric
 
 extern "C" {
 
-int pcs_abi_version(void) { return 100; }
+int pcs_abi_version(void) { return 101; }  // 101: workspace on pcs_mix_jacobian, row order on pcs_gc_bubble_dew / pcs_gc_jacobian
 
 const char* pcs_last_error(void) { return g_err; }
 
