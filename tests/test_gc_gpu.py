@@ -161,3 +161,45 @@ def test_ffi_mirror_and_errors(amd, oracle, table, gg):
     # two associating segments in one molecule -> the reference's exception (gc_pcsaft.py:77-80)
     with pytest.raises(Exception, match="one associating segment"):
         amd.GcPcSaftMix(*parse_segments(table), [[["OH", "CH2", "OH"], ["CH3", "CH3"]]], [[[[0, 1], [1, 2]], [[0, 1]]]], [])
+
+
+@pytest.mark.parametrize("dew", [False, True])
+def test_bad_rows_fail_cleanly(amd, table, dew):
+    """NaN / inf / non-physical temperature, composition, phi or initial pressure in some rows: the kernels terminate,
+    flag those rows and leave the other rows' results untouched; with and without the class order."""
+    from feos_torch_amd import native
+    from feos_torch_amd.gc_pcsaft import build_table, encode_rows
+    from feos_torch_amd.synthetic import gc_batch
+
+    n = 4096
+    b = gc_batch(n, table, seed=67)
+    ident = [s for s, _ in table]
+    rows = torch.from_numpy(encode_rows(ident, b["segment_lists"], b["bond_lists"])).cuda()
+    seg = torch.tensor(np.stack([v for _, v in table]), dtype=f64)
+    kab = torch.zeros((len(ident), len(ident)), dtype=f64)
+    for s1, s2, k in b["kab_list"]:
+        kab[ident.index(s1), ident.index(s2)] = k
+        kab[ident.index(s2), ident.index(s1)] = k
+    tab = build_table(seg.cuda(), kab.cuda())
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    order = native.gc_class_order(tab, len(ident), rows)
+    ref = native.gc_bubble_dew(tab, len(ident), rows, d(b["phi"]), d(b["T"]), d(b["x"]), d(b["p_init"]), dew, order=order)
+    phi, T, x, p0 = b["phi"].copy(), b["T"].copy(), b["x"].copy(), b["p_init"].copy()
+    bad = np.arange(0, n, 41)
+    kinds = [lambda i: T.__setitem__(i, np.nan), lambda i: T.__setitem__(i, -10.0), lambda i: T.__setitem__(i, np.inf),
+             lambda i: x.__setitem__(i, 0.0), lambda i: x.__setitem__(i, 1.0), lambda i: x.__setitem__(i, np.nan),
+             lambda i: phi.__setitem__((i, 0), np.nan), lambda i: phi.__setitem__((i, 1), -1.0), lambda i: p0.__setitem__(i, np.inf),
+             lambda i: p0.__setitem__(i, -1.0), lambda i: T.__setitem__(i, 1e-3), lambda i: T.__setitem__(i, 1e6)]
+    for j, i in enumerate(bad):
+        kinds[j % len(kinds)](i)
+    good = np.ones(n, dtype=bool)
+    good[bad] = False
+    g = torch.from_numpy(good).cuda()
+    for o in (order, None):
+        r = native.gc_bubble_dew(tab, len(ident), rows, d(phi), d(T), d(x), d(p0), dew, order=o)
+        torch.cuda.synchronize()
+        assert torch.equal(r["status"][g], ref["status"][g]) and torch.equal(r["p"][g], ref["p"][g])
+        ok = ~r["status"]
+        assert bool(torch.isfinite(r["p"][ok]).all()) and bool((r["p"][ok] > 0).all())
+        hopeless = torch.from_numpy(np.isin(np.arange(n), bad[[j for j in range(len(bad)) if j % len(kinds) in (0, 1, 2, 5, 6)]])).cuda()
+        assert bool(r["status"][hopeless].all())

@@ -233,3 +233,36 @@ def test_empty_and_ffi_mirror(amd, oracle):
     assert np.max(np.abs(rho / want[~st] - 1)) < 1e-7
     rho_d, status_d = amd.PcSaft.dew_point(par, kij, T, np.full(3, 0.5), np.full(3, 1e5))
     assert rho_d.shape == (2, 4) and status_d.tolist() == [False, True, False]
+
+
+@pytest.mark.parametrize("dew", [False, True])
+def test_bad_rows_fail_cleanly(amd, dew):
+    """NaN / inf / non-physical inputs in some rows: the kernels terminate, flag exactly those rows (plus whatever has no
+    solution anyway) and leave the results of the other rows untouched (rows are independent)."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import mix_batch
+
+    n = 4096
+    P, K, T, X, PI = mix_batch(n, seed=61)
+    ref = native.mix_bubble_dew(_t(P).cuda(), _t(K).cuda(), _t(T).cuda(), _t(X).cuda(), _t(PI).cuda(), dew)
+    P2, K2, T2, X2, PI2 = P.copy(), K.copy(), T.copy(), X.copy(), PI.copy()
+    bad = np.arange(0, n, 37)
+    kinds = [lambda i: T2.__setitem__(i, np.nan), lambda i: T2.__setitem__(i, -10.0), lambda i: T2.__setitem__(i, np.inf),
+             lambda i: X2.__setitem__(i, 0.0), lambda i: X2.__setitem__(i, 1.0), lambda i: X2.__setitem__(i, np.nan),
+             lambda i: P2.__setitem__((i, 0, 0), np.nan), lambda i: P2.__setitem__((i, 1, 1), 0.0), lambda i: P2.__setitem__((i, 0, 2), -5.0),
+             lambda i: PI2.__setitem__(i, np.inf), lambda i: PI2.__setitem__(i, -1.0), lambda i: K2.__setitem__((i, 0), np.nan),
+             lambda i: T2.__setitem__(i, 1e-3), lambda i: T2.__setitem__(i, 1e6)]
+    for j, i in enumerate(bad):
+        kinds[j % len(kinds)](i)
+    r = native.mix_bubble_dew(_t(P2).cuda(), _t(K2).cuda(), _t(T2).cuda(), _t(X2).cuda(), _t(PI2).cuda(), dew)
+    torch.cuda.synchronize()
+    good = np.ones(n, dtype=bool)
+    good[bad] = False
+    g = torch.from_numpy(good).cuda()
+    assert torch.equal(r["status"][g], ref["status"][g])
+    assert torch.equal(r["p"][g], ref["p"][g])
+    ok = ~r["status"]
+    assert bool(torch.isfinite(r["p"][ok]).all()) and bool((r["p"][ok] > 0).all())
+    # the rows with NaN / inf / negative temperature or parameters can never converge
+    hopeless = torch.from_numpy(np.isin(np.arange(n), bad[[j for j in range(len(bad)) if j % len(kinds) in (0, 1, 2, 5, 6, 11)]])).cuda()
+    assert bool(r["status"][hopeless].all())
