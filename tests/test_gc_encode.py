@@ -93,3 +93,43 @@ def test_edge_cases(table):
         encode_rows_py(ident, [[nine, ["CH3"]]], [[[], []]])
     with pytest.raises(ValueError):
         encode_rows(ident, [[["CH3"] * 256, ["CH3"]]], [[[], []]])  # multiplicity above 255
+
+
+def test_class_order_is_a_permutation_sorted_by_class():
+    """native.gc_class_order (pure torch, any device): a permutation of the rows, association class x polarity
+    non-increasing along it (expensive classes first), ties by bond- and segment-type entry counts."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from feos_torch_amd import native
+    from feos_torch_amd.gc_pcsaft import build_table, encode_rows
+    from feos_torch_amd.synthetic import gc_batch, load_segment_table
+
+    table = load_segment_table(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "sauer2014_hetero.json"))
+    n = 5000
+    b = gc_batch(n, table, seed=5)
+    ident = [s for s, _ in table]
+    rows = torch.from_numpy(encode_rows(ident, b["segment_lists"], b["bond_lists"]))
+    seg = torch.tensor(np.stack([v for _, v in table]), dtype=torch.float64)
+    tab = build_table(seg, torch.zeros((len(ident), len(ident)), dtype=torch.float64))
+    order = native.gc_class_order(tab, len(ident), rows)
+    assert order.dtype == torch.int32 and sorted(order.tolist()) == list(range(n))
+    segv = seg.numpy()
+    ids, cnt = rows[:, 0:16].numpy().astype(int), rows[:, 16:32].numpy().astype(float)
+    par = segv[ids]
+
+    def per_mol(v):
+        return (cnt * v).reshape(n, 2, 8).sum(axis=2)
+
+    associating = ((per_mol(par[:, :, 4]) * per_mol(par[:, :, 5])) != 0).sum(axis=1)
+    self_assoc = ((per_mol(par[:, :, 6]) * per_mol(par[:, :, 7])) != 0).sum(axis=1)
+    cls = np.zeros(n, int)
+    cls[(associating == 1) & (self_assoc == 1)] = 1
+    cls[(associating == 2) & (self_assoc == 1)] = 2
+    cls[(associating == 2) & (self_assoc == 2)] = 3
+    key = 2 * cls + (per_mol(par[:, :, 3] ** 2) > 0).any(axis=1)
+    k = key[order.numpy()]
+    assert np.all(k[:-1] >= k[1:])
+    assert len(np.unique(key)) >= 3  # the synthetic library really mixes classes
