@@ -236,4 +236,134 @@ PCS_DEV R pure_a(const PureCoef<P>& c, const R& rho) {
     return a;
 }
 
+#ifndef PCS_D1S_CLOSED
+#define PCS_D1S_CLOSED 1
+#endif
+#if PCS_D1S_CLOSED
+// The pressure-only fp64 finish (R = D1s: a and a') with hard sphere, chain and dispersion in closed form, as the fp32
+// pre-solve does (pure_f32.hpp): a = rho F(eta) + rho^2 G(eta),
+//   F = m HS - (m-1) ln g,  HS = (4 eta - 3 eta^2) u^2,  HS' = (4 - 2 eta) u^3,  (ln g)' = 3u - w,  u = 1/(1-eta), w = 1/(2-eta)
+//   G = kd1 I1 + kd2 C I2,  C = 1/D,  D = 1 + m A - (m-1) B,  A' = (8 + 20 eta - 4 eta^2) u^5,  B' = q (poly' + 2 poly (u + w)), q = u^2 w^2
+template <>
+PCS_DEV D1s pure_a<double, D1s>(const PureCoef<double>& c, const D1s& rho) {
+    const double r = rho.v, eta = r * c.ceta;
+    const double u = d_recip(1.0 - eta), w = d_recip(2.0 - eta);
+    const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+    const double HS = eta * (4.0 - 3.0 * eta) * u2, HS1 = (4.0 - 2.0 * eta) * u3;
+    const double LG = d_log((1.0 - 0.5 * eta) * u3), LG1 = 3.0 * u - w;
+    const double F = c.m * HS - c.mm1 * LG, F1 = c.m * HS1 - c.mm1 * LG1;
+    const D1s e1(eta, 1.0);
+    const D1s I1 = horner_eta<7>(c.ai, e1), I2 = horner_eta<7>(c.bi, e1);  // value and eta-derivative
+    const double A = eta * (8.0 - 2.0 * eta) * u4, A1 = (8.0 + eta * (20.0 - 4.0 * eta)) * (u4 * u);
+    const double poly = eta * (20.0 + eta * (-27.0 + eta * (12.0 - 2.0 * eta)));
+    const double poly1 = 20.0 + eta * (-54.0 + eta * (36.0 - 8.0 * eta));
+    const double q = u2 * (w * w);
+    const double B = poly * q, B1 = q * (poly1 + 2.0 * poly * (u + w));
+    const double D = 1.0 + c.m * A - c.mm1 * B, D1_ = c.m * A1 - c.mm1 * B1;
+    const double C = d_recip(D), C1 = -D1_ * (C * C);
+    const double G = c.kd1 * I1.v + c.kd2 * (C * I2.v);
+    const double G1 = c.kd1 * I1.d1 + c.kd2 * (C1 * I2.v + C * I2.d1);
+    const double rc = r * c.ceta;
+    D1s a(r * (F + r * G), (F + rc * F1 + r * (2.0 * G + rc * G1)) * rho.d1);
+    if (c.polar || c.assoc) {
+        const D1s eta_d = rho * c.ceta;
+        if (c.polar) {
+            D1s J1 = horner_eta<5>(c.j1, eta_d);
+            D1s J2 = horner_eta<4>(c.j2, eta_d);
+            a = a + ((rho * rho) * c.qm) * ((J1 * J1) * d_recip(J1 - rho * J2));
+        }
+        if (c.assoc) {
+            D1s eta_m1 = d_recip(1.0 - eta_d);
+            D1s k = eta_d * eta_m1;
+            D1s delta = ((1.0 + k * (1.5 + 0.5 * k)) * eta_m1) * c.da;
+            D1s rhoa = rho * c.na;
+            D1s rhob = rho * c.nb;
+            D1s t = (rhob - rhoa) * delta;
+            D1s aux = 1.0 - t;
+            D1s sq = d_sqrt(aux * aux + 4.0 * (rhob * delta));
+            D1s xa, xb;  // conjugate forms, see pure_a above
+            const double tr = re(t);
+            if (tr > 0.5) {
+                xa = 2.0 * d_recip(sq + 1.0 + t);
+                xb = (sq - 1.0 + t) * d_recip(2.0 * (rhob * delta));
+            } else if (tr < -0.5) {
+                xa = (sq - 1.0 - t) * d_recip(2.0 * (rhoa * delta));
+                xb = 2.0 * d_recip(sq + 1.0 - t);
+            } else {
+                xa = 2.0 * d_recip(sq + 1.0 + t);
+                xb = 2.0 * d_recip(sq + 1.0 - t);
+            }
+            a = a + rhoa * site_term(xa) + rhob * site_term(xb);
+        }
+    }
+    return a;
+}
+
+// The same for R = D2<double> (a, a', a'': the solvers' Newton evaluations): second derivatives
+// HS'' = (10 - 4 eta) u^4, (ln g)'' = 3u^2 - w^2, A'' = (60 + 72 eta - 12 eta^2) u^6,
+// B'' = 2 q s (poly' + 2 poly s) + q (poly'' + 2 poly' s + 2 poly (u^2 + w^2)), s = u + w, C'' = (2 D'^2 C - D'') C^2.
+template <>
+PCS_DEV D2<double> pure_a<double, D2<double>>(const PureCoef<double>& c, const D2<double>& rho) {
+    const double r = rho.v, eta = r * c.ceta;
+    const double u = d_recip(1.0 - eta), w = d_recip(2.0 - eta);
+    const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2, w2 = w * w;
+    const double HS = eta * (4.0 - 3.0 * eta) * u2, HS1 = (4.0 - 2.0 * eta) * u3, HS2 = (10.0 - 4.0 * eta) * u4;
+    const double LG = d_log((1.0 - 0.5 * eta) * u3), LG1 = 3.0 * u - w, LG2 = 3.0 * u2 - w2;
+    const double F = c.m * HS - c.mm1 * LG, F1 = c.m * HS1 - c.mm1 * LG1, F2 = c.m * HS2 - c.mm1 * LG2;
+    const D2<double> e2(eta, 1.0, 0.0);
+    const D2<double> I1 = horner_eta<7>(c.ai, e2), I2 = horner_eta<7>(c.bi, e2);  // value, eta-derivatives
+    const double A = eta * (8.0 - 2.0 * eta) * u4, A1 = (8.0 + eta * (20.0 - 4.0 * eta)) * (u4 * u),
+                 A2 = (60.0 + eta * (72.0 - 12.0 * eta)) * (u4 * u2);
+    const double poly = eta * (20.0 + eta * (-27.0 + eta * (12.0 - 2.0 * eta)));
+    const double poly1 = 20.0 + eta * (-54.0 + eta * (36.0 - 8.0 * eta)), poly2 = -54.0 + eta * (72.0 - 24.0 * eta);
+    const double q = u2 * w2, sm = u + w;
+    const double tq = poly1 + 2.0 * poly * sm;
+    const double B = poly * q, B1 = q * tq, B2 = q * (2.0 * sm * tq + poly2 + 2.0 * poly1 * sm + 2.0 * poly * (u2 + w2));
+    const double D = 1.0 + c.m * A - c.mm1 * B, D1_ = c.m * A1 - c.mm1 * B1, D2_ = c.m * A2 - c.mm1 * B2;
+    const double C = d_recip(D), Csq = C * C;
+    const double C1 = -D1_ * Csq, C2 = (2.0 * D1_ * D1_ * C - D2_) * Csq;
+    const double G = c.kd1 * I1.v + c.kd2 * (C * I2.v);
+    const double G1 = c.kd1 * I1.d1 + c.kd2 * (C1 * I2.v + C * I2.d1);
+    const double G2 = c.kd1 * I1.d2 + c.kd2 * (C2 * I2.v + 2.0 * C1 * I2.d1 + C * I2.d2);
+    const double ce = c.ceta, rc = r * ce;
+    const double a0 = r * (F + r * G);
+    const double a1 = F + rc * F1 + r * (2.0 * G + rc * G1);
+    const double a2 = ce * (2.0 * F1 + rc * F2) + 2.0 * G + rc * (4.0 * G1 + rc * G2);
+    D2<double> a(a0, a1 * rho.d1, a2 * (rho.d1 * rho.d1) + a1 * rho.d2);
+    if (c.polar || c.assoc) {
+        typedef D2<double> R;
+        const R eta_d = rho * c.ceta;
+        if (c.polar) {
+            R J1 = horner_eta<5>(c.j1, eta_d);
+            R J2 = horner_eta<4>(c.j2, eta_d);
+            a = a + ((rho * rho) * c.qm) * ((J1 * J1) * d_recip(J1 - rho * J2));
+        }
+        if (c.assoc) {
+            R eta_m1 = d_recip(1.0 - eta_d);
+            R k = eta_d * eta_m1;
+            R delta = ((1.0 + k * (1.5 + 0.5 * k)) * eta_m1) * c.da;
+            R rhoa = rho * c.na;
+            R rhob = rho * c.nb;
+            R t = (rhob - rhoa) * delta;
+            R aux = 1.0 - t;
+            R sq = d_sqrt(aux * aux + 4.0 * (rhob * delta));
+            R xa, xb;  // conjugate forms, see pure_a above
+            const double tr = re(t);
+            if (tr > 0.5) {
+                xa = 2.0 * d_recip(sq + 1.0 + t);
+                xb = (sq - 1.0 + t) * d_recip(2.0 * (rhob * delta));
+            } else if (tr < -0.5) {
+                xa = (sq - 1.0 - t) * d_recip(2.0 * (rhoa * delta));
+                xb = 2.0 * d_recip(sq + 1.0 - t);
+            } else {
+                xa = 2.0 * d_recip(sq + 1.0 + t);
+                xb = 2.0 * d_recip(sq + 1.0 - t);
+            }
+            a = a + rhoa * site_term(xa) + rhob * site_term(xb);
+        }
+    }
+    return a;
+}
+#endif
+
 }  // namespace pcs
