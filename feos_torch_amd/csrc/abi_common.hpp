@@ -23,4 +23,19 @@ inline int check_n(int64_t n) {
 }
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Device-side counters (retry-list count, work-queue control block) are zeroed by a KERNEL on the call's stream, not by
+// hipMemsetAsync: every operation of a call is then a kernel node, so a hipGraph capture of the call replays them in
+// the captured order (a memset node is executed by the runtime's blit path, which round 1 saw reordered against the
+// kernels of a replay issued behind pending work).
+template <int DUMMY = 0>
+__global__ void k_zero_ints(int32_t* __restrict__ p, int count) {
+    for (int k = threadIdx.x; k < count; k += blockDim.x) p[k] = 0;
+}
+inline int zero_ints(int32_t* p, int count, hipStream_t s) {
+    hipLaunchKernelGGL(k_zero_ints<0>, dim3(1), dim3(64), 0, s, p, count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_zero_ints launch", e);
+    return 0;
+}
+
 }  // namespace pcs_abi

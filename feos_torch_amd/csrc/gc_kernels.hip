@@ -373,8 +373,7 @@ int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, 
     hipStream_t s = as_stream(stream);
     int32_t* retry = static_cast<int32_t*>(workspace);
     if (retry) {
-        hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);
-        if (e != hipSuccess) return fail("hipMemsetAsync", e);
+        if (int e = zero_ints(retry, 1, s)) return e;
     }
     if (dew) {
         hipLaunchKernelGGL((k_gc_bubble_dew<true, false>), dim3(grid), dim3(GBLOCK), lds, s, table, S, rows, phi, temp, z, p_init,

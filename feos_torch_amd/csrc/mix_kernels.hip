@@ -290,6 +290,7 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
     MixModel m;
     int64_t row = -1;
     double T = 0.0;
+    int evals = 0;  // evaluations of this lane's current row (bounded by BD_EVAL_GUARD: the loop below cannot hang)
 #if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
     int nev = 0, t_start = 0;  // diagnostics: evaluations of this lane's row, kernel-relative start time
     const long long t_kernel = clock64();
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
                 T = temp[row];
                 mix_coef<double>(m.c, par, k0, k1, T);
                 L.start(m, z[row], p_init[row] / (T * P_UNIT));
+                evals = 0;
 #if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
                 nev = 0;
                 t_start = (int)((clock64() - t_kernel) >> 14);
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
             L.point(e0, e1);
             PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
             L.consume(m, e);
+            if (++evals > BD_EVAL_GUARD && !L.done()) L.idle();  // rc = BD_FAILED
 #if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
             nev++;
             if (L.done()) L.out.iters = (nev & 4095) | ((t_start & 0xffff) << 12);
@@ -446,12 +449,12 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
         // work-queue schedule: perm[n] + control block in the workspace
         int32_t* perm = static_cast<int32_t*>(workspace);
         int32_t* ctrl = perm + n;
-        hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int32_t) * QCTRL_INTS, s);
-        if (e != hipSuccess) return fail("hipMemsetAsync", e);
+        if (int ez = zero_ints(ctrl, QCTRL_INTS, s)) return ez;
         const unsigned g256 = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);
         hipLaunchKernelGGL(k_mix_class_scan, dim3(1), dim3(64), 0, s, ctrl);
         hipLaunchKernelGGL(k_mix_class_scatter, dim3(g256), dim3(256), 0, s, params, n, ctrl, perm);
+        hipError_t e;
         unsigned waves = (unsigned)queue_waves();
         const unsigned needed = (unsigned)((n + 63) / 64);
         if (waves > needed) waves = needed;
@@ -468,8 +471,7 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
 #endif
     int32_t* retry = static_cast<int32_t*>(workspace);
     if (retry) {
-        hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);
-        if (e != hipSuccess) return fail("hipMemsetAsync", e);
+        if (int ez = zero_ints(retry, 1, s)) return ez;
     }
     if (dew) {
         hipLaunchKernelGGL(k_mix_bubble_dew<true>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
@@ -515,8 +517,7 @@ int pcs_mix_jacobian(int dew, const double* params, const double* kij, const dou
     if (workspace) {  // batch-wide class order (the permutation of the work-queue schedule)
         int32_t* perm = static_cast<int32_t*>(workspace);
         int32_t* ctrl = perm + n;
-        hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int32_t) * QCTRL_INTS, s);
-        if (e != hipSuccess) return fail("hipMemsetAsync", e);
+        if (int ez = zero_ints(ctrl, QCTRL_INTS, s)) return ez;
         const unsigned g256 = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);
         hipLaunchKernelGGL(k_mix_class_scan, dim3(1), dim3(64), 0, s, ctrl);

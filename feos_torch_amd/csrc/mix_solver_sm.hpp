@@ -301,15 +301,19 @@ struct BdLane {
     }
 };
 
+// Upper bound of the evaluations one row can need: 2 pure roots + (SS_MAX_IT sweeps each with a double root re-solve)
+// + 2 evaluations per Newton iteration.  Every driver of the state machine (single pass below, work queue in
+// mix_kernels.hip) gives a row up beyond it, so a stage transition that fails to advance a counter fails the row
+// instead of hanging the wave.
+constexpr int BD_EVAL_GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MAX_IT + 2) + 2 * NEWTON_MAX_IT + 8;
+
 // One row per lane: every pass of the wave-level loop evaluates once for every unfinished lane.
 template <bool DEW, class Model>
 PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
                                 int newton_max = NEWTON_MAX_IT) {
     BdLane<DEW> L;
     L.start(m, z0, p_init, ss_max, newton_max);
-    // worst case: 2 pure roots + (SS_MAX_IT sweeps each with a double root re-solve) + 2 evaluations per Newton iteration
-    constexpr int GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MAX_IT + 2) + 2 * NEWTON_MAX_IT + 8;
-    for (int guard = 0; guard < GUARD; guard++) {
+    for (int guard = 0; guard < BD_EVAL_GUARD; guard++) {
         if (__ballot(!L.done()) == 0ull) break;
         if (L.done()) continue;
         double e0, e1;

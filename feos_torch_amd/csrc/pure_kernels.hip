@@ -363,8 +363,8 @@ int64_t pcs_workspace_bytes(int64_t n) { return (int64_t)sizeof(int32_t) * (n + 
 // stage 1: zero the retry counter and run the fast kernel over all rows
 static int launch_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
                            double* rho_vl, uint8_t* status, int32_t* iters, int32_t* retry, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(retry, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) return fail("hipMemsetAsync", e);
+    if (int ez = zero_ints(retry, 1, s)) return ez;
+    hipError_t e;
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
 #if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
     // main kernel (lean: rows without an fp32 pre-solve go to the list with bit 31 set) + all-fp64 fallback kernel.

@@ -37,6 +37,14 @@ def _prep(x, device, shape_tail=None):
     return x
 
 
+def _same_rows(n, **named):
+    """Every row-wise argument must have n rows: the kernels launch n lanes over all of them (the reference raises a
+    shape error in the same situation, e.g. a model reduced by an earlier property call used with the original T)."""
+    for name, t in named.items():
+        if t is not None and t.shape[0] != n:
+            raise ValueError(f"{name} has {t.shape[0]} rows, expected {n}")
+
+
 def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=False, want_rho_vl=True):
     """Pure VLE on the GPU.  -> dict(p_sat [Pa], rho_eq [kmol/m3], rho_vl [n,2] A^-3, status bool, iters).
     want_rho_vl=False with want_rho_eq=False selects the pressure-only kernel (fp64 finish with the fp32
@@ -90,6 +98,7 @@ def pure_derivatives(params, temperature, density):
     temperature = _prep(temperature, device)
     density = _prep(density, device)
     n = temperature.shape[0]
+    _same_rows(n, parameters=params, density=density)
     L = _lib.lib()
     with torch.cuda.device(device):
         a = torch.empty(n, dtype=_F64, device=device)
@@ -112,6 +121,7 @@ def pure_jacobian(which, params, temperature, pressure, rho_vl):
     pressure = None if pressure is None else _prep(pressure, device)
     rho_vl = _prep(rho_vl, device, (2,))
     n = temperature.shape[0]
+    _same_rows(n, parameters=params, pressure=pressure, rho_vl=rho_vl)
     L = _lib.lib()
     with torch.cuda.device(device):
         jac = torch.empty((n, 10), dtype=_F64, device=device)
@@ -234,6 +244,7 @@ def mix_derivatives(params, kij, temperature, density):
     temperature = _prep(temperature, device)
     density = _prep(density, device, (2,))
     n = temperature.shape[0]
+    _same_rows(n, parameters=params, kij=kij, density=density)
     L = _lib.lib()
     with torch.cuda.device(device):
         a = torch.empty(n, dtype=_F64, device=device)
@@ -278,6 +289,7 @@ def mix_jacobian(params, kij, temperature, rho4, dew):
     temperature = _prep(temperature, device)
     rho4 = _prep(rho4, device, (4,))
     n = temperature.shape[0]
+    _same_rows(n, parameters=params, kij=kij, rho4=rho4)
     L = _lib.lib()
     with torch.cuda.device(device):
         jac = torch.empty((n, 19), dtype=_F64, device=device)
@@ -291,6 +303,18 @@ def mix_jacobian(params, kij, temperature, rho4, dew):
 # ------------------------------------------------------------------------------------------
 # heterosegmented gc-PC-SAFT
 # ------------------------------------------------------------------------------------------
+def _check_gc(table, S, rows, n):
+    """table / row encoding of include/pcsaft_hip.h on one device, n rows."""
+    S = int(S)
+    if table.dtype != _F64 or table.dim() != 1 or table.shape[0] != S * 8 + 3 * S * S or not table.is_contiguous():
+        raise ValueError(f"table must be a contiguous float64 tensor of {S * 8 + 3 * S * S} elements for S = {S}")
+    if rows.dtype != torch.uint8 or rows.dim() != 2 or rows.shape[1] != 80 or not rows.is_contiguous():
+        raise ValueError("rows must be a contiguous uint8 tensor [n, 80]")
+    if rows.device != table.device:
+        raise ValueError(f"rows live on {rows.device}, the segment table on {table.device}")
+    _same_rows(n, rows=rows)
+
+
 def gc_class_order(table, S, rows):
     """Permutation (position -> row, int32 on the device) that sorts the rows of a gc model by model class — association
     class x polarity, expensive classes first — for the `order` argument of gc_bubble_dew.  The rows of a model are
@@ -331,6 +355,8 @@ def gc_bubble_dew(table, S, rows, phi, temperature, molefracs, pressure, dew, wa
     molefracs = _prep(molefracs, device)
     pressure = _prep(pressure, device)
     n = temperature.shape[0]
+    _check_gc(table, S, rows, n)
+    _same_rows(n, phi=phi, molefracs=molefracs, pressure=pressure)
     if order is not None and (order.dtype != torch.int32 or order.shape != (n,) or order.device != device or not order.is_contiguous()):
         raise ValueError("order must be a contiguous int32 tensor [n] on the device of the table")
     L = _lib.lib()
@@ -354,6 +380,8 @@ def gc_derivatives(table, S, rows, phi, temperature, density):
     temperature = _prep(temperature, device)
     density = _prep(density, device, (2,))
     n = temperature.shape[0]
+    _check_gc(table, S, rows, n)
+    _same_rows(n, phi=phi, density=density)
     L = _lib.lib()
     with torch.cuda.device(device):
         a = torch.empty(n, dtype=_F64, device=device)
@@ -374,6 +402,8 @@ def gc_jacobian(table, S, rows, phi, temperature, rho4, dew, order=None):
     temperature = _prep(temperature, device)
     rho4 = _prep(rho4, device, (4,))
     n = temperature.shape[0]
+    _check_gc(table, S, rows, n)
+    _same_rows(n, phi=phi, rho4=rho4)
     L = _lib.lib()
     with torch.cuda.device(device):
         jac = torch.empty((n, 7), dtype=_F64, device=device)

@@ -103,3 +103,36 @@ def test_kernel_stack_frames_and_occupancy(hip_lib):
     for name, r in res.items():
         if "k_pure_vle" in name or "k_pure_liquid_density" in name or "k_pure_derivatives" in name:
             assert r["scratch"] == 0, (name, r)
+
+
+def test_row_count_validation_is_host_side():
+    """The kernels launch one lane per temperature over every row-wise argument, so the wrappers must refuse any
+    argument with another number of rows before launching (the reference raises a shape error there; easy to hit: every
+    property call reduces the model, so a later `derivatives(T, rho)` with the original T is one row too long)."""
+    import torch
+
+    from feos_torch_amd import native
+
+    f64 = torch.float64
+    native._same_rows(4, parameters=torch.zeros((4, 8), dtype=f64), density=torch.zeros(4, dtype=f64), pressure=None)
+    with pytest.raises(ValueError, match="parameters has 3 rows, expected 4"):
+        native._same_rows(4, parameters=torch.zeros((3, 8), dtype=f64), density=torch.zeros(4, dtype=f64))
+    with pytest.raises(ValueError, match="rho4 has 5 rows"):
+        native._same_rows(4, rho4=torch.zeros((5, 4), dtype=f64))
+    S = 3
+    table = torch.zeros(S * 8 + 3 * S * S, dtype=f64)
+    rows = torch.zeros((4, 80), dtype=torch.uint8)
+    native._check_gc(table, S, rows, 4)
+    with pytest.raises(ValueError, match="rows has 4 rows, expected 5"):
+        native._check_gc(table, S, rows, 5)
+    with pytest.raises(ValueError, match="table must be"):
+        native._check_gc(table[:-1], S, rows, 4)
+    with pytest.raises(ValueError, match="rows must be"):
+        native._check_gc(table, S, rows[:, :79], 4)
+    # every device-level wrapper validates (source check: a new wrapper without a row check is the bug this guards)
+    import inspect
+
+    for name in ("pure_vle", "pure_liquid_density", "pure_derivatives", "pure_jacobian", "mix_bubble_dew", "mix_derivatives",
+                 "mix_jacobian", "gc_bubble_dew", "gc_derivatives", "gc_jacobian"):
+        src = inspect.getsource(getattr(native, name))
+        assert "_same_rows(" in src or "differ in length" in src, name

@@ -392,3 +392,44 @@ def test_retry_pass_survives_a_foreign_work_list(amd):
     torch.cuda.synchronize()
     assert torch.equal(plan.status, ref_s)
     assert torch.allclose(plan.p_sat, ref_p, rtol=1e-9, atol=0.0)
+
+
+def test_hipgraph_replay_behind_pending_work_equals_eager(amd):
+    """A hipGraph capture of pcs_pure_vle (counter reset, main kernel, fp64 fallback, robust pass) replayed while earlier
+    launches are still pending on the stream must reproduce the eager results bit for bit.  Every operation of the call
+    is a kernel node (the counter is zeroed by a kernel, not by hipMemsetAsync), so the replay keeps the captured
+    order; the list consumers bound count and entries by n, so even a mis-ordered replay could not fault — it would
+    show up here as a mismatch."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch
+
+    n = 300_000
+    P, T = pure_batch(n, seed=611)
+    P[:50, 2] *= 1.9  # a few near-/super-critical rows: the fallback and robust passes have work
+    dev = torch.device("cuda:0")
+    par, tem = torch.from_numpy(P).to(dev), torch.from_numpy(T).to(dev)
+    plan = native.PureVlePlan(n, dev, want_rho_eq=True, want_rho_vl=True)
+    plan.run(par, tem)
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in (plan.p_sat, plan.rho_eq, plan.rho_vl, plan.status)]
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):  # warm-up on the capture stream, as torch recommends
+        plan.run(par, tem)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        plan.run(par, tem)
+    other = native.PureVlePlan(n, dev, want_rho_vl=True)
+    for rep in range(3):
+        for t in (plan.p_sat, plan.rho_eq, plan.rho_vl):
+            t.fill_(float("nan"))
+        plan.status.fill_(7)
+        plan.ws.fill_(0x7FFFFFF0)  # stale list: a consumer that ran before the reset would see it
+        for _ in range(4):  # pending work ahead of the replay
+            other.run(par, tem)
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, want in zip((plan.p_sat, plan.rho_eq, plan.rho_vl, plan.status), ref):
+            assert torch.equal(got, want), rep
