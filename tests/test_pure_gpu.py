@@ -405,7 +405,8 @@ def test_hipgraph_replay_behind_pending_work_equals_eager(amd):
 
     n = 300_000
     P, T = pure_batch(n, seed=611)
-    P[:50, 2] *= 1.9  # a few near-/super-critical rows: the fallback and robust passes have work
+    T[:25] *= 1.5   # super-critical rows (fail in every pass)
+    T[25:80] *= 1.2  # near-critical rows: the fallback and robust passes have work
     dev = torch.device("cuda:0")
     par, tem = torch.from_numpy(P).to(dev), torch.from_numpy(T).to(dev)
     plan = native.PureVlePlan(n, dev, want_rho_eq=True, want_rho_vl=True)
