@@ -8,6 +8,7 @@
 #include "../../include/pcsaft_hip.h"
 #include "abi_common.hpp"
 #include "gc_model.hpp"
+#include "gc_kernel_common.hpp"
 #include "mix_solver.hpp"
 #include "mix_solver_sm.hpp"
 #ifndef PCS_MIX_SM
@@ -29,27 +30,6 @@ namespace {
 #endif
 constexpr int GBLOCK = PCS_GBLOCK;
 constexpr int GJBLOCK = 64;
-
-template <class P>
-struct GcModelT {
-    GcCoef<P> c;
-    template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return gc_a<P, R>(c, r0, r1); }
-    PCS_DEV double packing(double x0, double x1) const { return x0 * re(c.zk[3][0]) + x1 * re(c.zk[3][1]); }
-};
-
-// stage the batch table (S*8 + 3*S*S doubles) into LDS
-__device__ __forceinline__ GcTable stage_table(const double* __restrict__ table, int S, double* lds) {
-    const int nd = gc_table_doubles(S);
-    for (int k = threadIdx.x; k < nd; k += blockDim.x) lds[k] = table[k];
-    __syncthreads();
-    GcTable tb;
-    tb.S = S;
-    tb.seg = lds;
-    tb.E1 = lds + S * 8;
-    tb.E2 = tb.E1 + S * S;
-    tb.K = tb.E2 + S * S;
-    return tb;
-}
 
 #ifndef PCS_GC_BUCKET
 #define PCS_GC_BUCKET 1
@@ -220,12 +200,6 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_derivatives(const double* __restr
 constexpr int GC_DIRS = 7;   // A00, A01, A11, B00, B01, B11, T
 constexpr int GC_CHUNK = 1;  // the only dual-number direction left is T
 
-// the one dual-number evaluation site of the Jacobian kernel, not inlined (register pressure, see mix_jacobian.hpp)
-template <class G, class R>
-__device__ __attribute__((noinline)) R gc_a_tangent(const GcCoef<G>& c, const R& r0, const R& r1) {
-    return gc_a<G, R>(c, r0, r1);
-}
-
 __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* __restrict__ table, int S,
                                                          const unsigned char* __restrict__ rows,
                                                          const double* __restrict__ phi,
@@ -343,16 +317,6 @@ __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* 
         const double dp = (dew ? dpS : dpI) - (w[0] * dF0 + w[1] * dF1 + w[2] * (dpS - dpI));
         g[6] = ok ? dp * T * P_UNIT + p_red * P_UNIT : nanv;
     }
-}
-
-size_t gc_lds_bytes(int S, int block, int per_thread_doubles) {
-    return sizeof(double) * ((size_t)(S * 8 + 3 * S * S) + (size_t)per_thread_doubles * block);
-}
-
-int gc_check(int S, int64_t n) {
-    if (int e = check_n(n)) return e;
-    if (S < 1 || S > GC_MAXS) return fail_msg("gc: number of segment types must be in [1, 32]");
-    return 0;
 }
 
 }  // namespace

@@ -53,80 +53,85 @@ struct GcCoef {
 
 PCS_DEV double sgn_d(double x) { return (x > 0.0) - (x < 0.0); }
 
-// row = 80 bytes of structure (see header); aggregates for i != j use K, E1, E2 tables.
+// Molecule-level sums of a row: everything the model needs from the segment table besides the bond diameters.
+// P = type of the temperature-dependent sums, Q = type of the others (double in the solvers; the segment-parameter
+// gradient kernel seeds tangents on all of them: P = Q = DN).
+template <class P, class Q>
+struct GcMol {
+    Q M[2];                                       // sum n m                               (:55, :66)
+    P Zk[3][2];                                   // sum n m d^k, k = 1..3                 (:122-131)
+    Q S3[2], EK[2], MU[2];                        // sum n m sigma^3, sum n m eps, sum n mu^2   (:66-73)
+    Q sa[2], ea[2], ka[2], eab[2], na[2], nb[2];  // association picks / sums              (:76-86)
+    Q s1[3], s2[3];                               // dispersion double sums, pairs 00, 01, 11 (:177-194) without phi and T
+};
+
+// segment diameter (:118-120)
 template <class P>
-PCS_DEV void gc_coef(GcCoef<P>& c, const unsigned char* row, const GcTable& tb, double phi0, double phi1, const P& T) {
-    P rT = d_recip(T);
-    double mtot[2], s3sum[2], eksum[2], mu2sum[2], sa[2], ea[2], ka[2], eabs[2], nas[2], nbs[2];
-    P zk[4][2];
+PCS_DEV P gc_diameter(const double* seg, const P& rT) { return seg[1] * (1.0 - 0.12 * d_exp((-3.0 * seg[2]) * rT)); }
+
+// row = 80 bytes of structure (see header) -> molecule-level sums; also fills the lane's bond list (d_ab, count)
+template <class P>
+PCS_DEV void gc_mol(GcMol<P, double>& ml, P* bond_dab, double* bond_cnt, int stride, const unsigned char* row, const GcTable& tb,
+                    const P& rT) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        mtot[i] = s3sum[i] = eksum[i] = mu2sum[i] = sa[i] = ea[i] = ka[i] = eabs[i] = nas[i] = nbs[i] = 0.0;
-        zk[0][i] = P(0.0); zk[1][i] = P(0.0); zk[2][i] = P(0.0); zk[3][i] = P(0.0);
+        double mtot = 0.0, s3sum = 0.0, eksum = 0.0, mu2sum = 0.0, sa = 0.0, ea = 0.0, ka = 0.0, eabs = 0.0, nas = 0.0, nbs = 0.0;
+        P z1(0.0), z2(0.0), z3(0.0);
 #pragma unroll 1
         for (int e = 0; e < GC_MAXE; e++) {
             const int n = row[16 + i * GC_MAXE + e];
             if (n == 0) continue;
             const double* p = tb.seg + 8 * row[i * GC_MAXE + e];
             const double ma = n * p[0];
-            P d = p[1] * (1.0 - 0.12 * d_exp((-3.0 * p[2]) * rT));  // :118-120
-            zk[0][i] = zk[0][i] + ma;
-            zk[1][i] = zk[1][i] + ma * d;
-            zk[2][i] = zk[2][i] + ma * (d * d);
-            zk[3][i] = zk[3][i] + ma * (d * d * d);
-            mtot[i] += ma;
-            s3sum[i] += ma * p[1] * p[1] * p[1];
-            eksum[i] += ma * p[2];
-            mu2sum[i] += n * p[3] * p[3];
+            P d = gc_diameter<P>(p, rT);
+            z1 = z1 + ma * d;
+            z2 = z2 + ma * (d * d);
+            z3 = z3 + ma * (d * d * d);
+            mtot += ma;
+            s3sum += ma * p[1] * p[1] * p[1];
+            eksum += ma * p[2];
+            mu2sum += n * p[3] * p[3];
             const double ia = n * sgn_d(p[4] * p[5]);
-            sa[i] += ia * p[1];
-            ea[i] += ia * p[2];
-            ka[i] += n * p[4];
-            eabs[i] += n * p[5];
-            nas[i] += n * p[6];
-            nbs[i] += n * p[7];
+            sa += ia * p[1];
+            ea += ia * p[2];
+            ka += n * p[4];
+            eabs += n * p[5];
+            nas += n * p[6];
+            nbs += n * p[7];
         }
-        c.m[i] = P(mtot[i]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) c.zk[k][i] = zk[k][i] * FRAC_PI_6;  // :122-131
+        ml.M[i] = mtot; ml.Zk[0][i] = z1; ml.Zk[1][i] = z2; ml.Zk[2][i] = z3;
+        ml.S3[i] = s3sum; ml.EK[i] = eksum; ml.MU[i] = mu2sum;
+        ml.sa[i] = sa; ml.ea[i] = ea; ml.ka[i] = ka; ml.eab[i] = eabs; ml.na[i] = nas; ml.nb[i] = nbs;
     }
-    // dispersion aggregates (:177-194): A_ij = sqrt(phi_i phi_j)/T sum m_ia m_jb E1_ab (1-k_ab)[i!=j]
-    {
-        double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
+    // dispersion double sums (:177-194): sum m_ia m_jb E1_ab (1-k_ab)[i!=j], likewise E2 with (1-k_ab)^2
 #pragma unroll
-        for (int pr = 0; pr < 3; pr++) {
-            const int i = (pr == 2) ? 1 : 0, j = (pr == 0) ? 0 : 1;
+    for (int pr = 0; pr < 3; pr++) {
+        const int i = (pr == 2) ? 1 : 0, j = (pr == 0) ? 0 : 1;
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll 1
-            for (int e = 0; e < GC_MAXE; e++) {
-                const int na_ = row[16 + i * GC_MAXE + e];
-                if (na_ == 0) continue;
-                const int ia = row[i * GC_MAXE + e];
-                const double ma = na_ * tb.seg[8 * ia];
+        for (int e = 0; e < GC_MAXE; e++) {
+            const int na_ = row[16 + i * GC_MAXE + e];
+            if (na_ == 0) continue;
+            const int ia = row[i * GC_MAXE + e];
+            const double ma = na_ * tb.seg[8 * ia];
 #pragma unroll 1
-                for (int f = 0; f < GC_MAXE; f++) {
-                    const int nb_ = row[16 + j * GC_MAXE + f];
-                    if (nb_ == 0) continue;
-                    const int ib = row[j * GC_MAXE + f];
-                    const double mm = ma * (nb_ * tb.seg[8 * ib]);
-                    double t1 = tb.E1[ia * tb.S + ib], t2 = tb.E2[ia * tb.S + ib];
-                    if (i != j) {
-                        const double k = tb.K[ia * tb.S + ib];
-                        t1 *= k;
-                        t2 *= k * k;
-                    }
-                    s1[pr] += mm * t1;
-                    s2[pr] += mm * t2;
+            for (int f = 0; f < GC_MAXE; f++) {
+                const int nb_ = row[16 + j * GC_MAXE + f];
+                if (nb_ == 0) continue;
+                const int ib = row[j * GC_MAXE + f];
+                const double mm = ma * (nb_ * tb.seg[8 * ib]);
+                double t1 = tb.E1[ia * tb.S + ib], t2 = tb.E2[ia * tb.S + ib];
+                if (i != j) {
+                    const double k = tb.K[ia * tb.S + ib];
+                    t1 *= k;
+                    t2 *= k * k;
                 }
+                s1 += mm * t1;
+                s2 += mm * t2;
             }
         }
-        const double p00 = phi0, p01 = sqrt(phi0 * phi1), p11 = phi1;
-        P rT2 = rT * rT;
-        c.A[0] = rT * (p00 * s1[0]);
-        c.A[1] = rT * (2.0 * p01 * s1[1]);
-        c.A[2] = rT * (p11 * s1[2]);
-        c.B[0] = rT2 * (p00 * p00 * s2[0]);
-        c.B[1] = rT2 * (2.0 * phi0 * phi1 * s2[1]);
-        c.B[2] = rT2 * (p11 * p11 * s2[2]);
+        ml.s1[pr] = s1;
+        ml.s2[pr] = s2;
     }
     // bonds (:156-165): d_ab = d_a d_b / (d_a + d_b) per bond-type entry
 #pragma unroll
@@ -134,58 +139,89 @@ PCS_DEV void gc_coef(GcCoef<P>& c, const unsigned char* row, const GcTable& tb, 
 #pragma unroll 1
         for (int e = 0; e < GC_MAXE; e++) {
             const int n = row[64 + i * GC_MAXE + e];
-            const int slot = (i * GC_MAXE + e) * c.stride;
-            c.bond_cnt[slot] = (double)n;
+            const int slot = (i * GC_MAXE + e) * stride;
+            bond_cnt[slot] = (double)n;
             if (n == 0) continue;
-            const double* pa = tb.seg + 8 * row[32 + i * GC_MAXE + e];
-            const double* pb = tb.seg + 8 * row[48 + i * GC_MAXE + e];
-            P da = pa[1] * (1.0 - 0.12 * d_exp((-3.0 * pa[2]) * rT));
-            P db = pb[1] * (1.0 - 0.12 * d_exp((-3.0 * pb[2]) * rT));
-            c.bond_dab[slot] = (da * db) * d_recip(da + db);
+            P da = gc_diameter<P>(tb.seg + 8 * row[32 + i * GC_MAXE + e], rT);
+            P db = gc_diameter<P>(tb.seg + 8 * row[48 + i * GC_MAXE + e], rT);
+            bond_dab[slot] = (da * db) * d_recip(da + db);
         }
     }
+}
+
+// molecule-level sums -> coefficients of gc_a (bond list aside).  Either Q = double or Q = P.
+template <class P, class Q>
+PCS_DEV void gc_finish(GcCoef<P>& c, const GcMol<P, Q>& ml, double phi0, double phi1, const P& rT) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        c.m[i] = P(ml.M[i]);
+        c.zk[0][i] = P(ml.M[i] * FRAC_PI_6);  // :122-131
+#pragma unroll
+        for (int k = 1; k < 4; k++) c.zk[k][i] = ml.Zk[k - 1][i] * FRAC_PI_6;
+    }
+    // dispersion aggregates (:177-194): A_ij = sqrt(phi_i phi_j)/T sum m_ia m_jb E1_ab (1-k_ab)[i!=j]
+    {
+        const double p00 = phi0, p01 = sqrt(phi0 * phi1), p11 = phi1;
+        P rT2 = rT * rT;
+        c.A[0] = rT * (p00 * ml.s1[0]);
+        c.A[1] = rT * (2.0 * p01 * ml.s1[1]);
+        c.A[2] = rT * (p11 * ml.s1[2]);
+        c.B[0] = rT2 * (p00 * p00 * ml.s2[0]);
+        c.B[1] = rT2 * (2.0 * phi0 * phi1 * ml.s2[1]);
+        c.B[2] = rT2 * (p11 * p11 * ml.s2[2]);
+    }
     // dipoles: molecule-level averages (:66-73), mu2_term = mu2/T (:262)
-    c.polar = (mu2sum[0] > 0.0) || (mu2sum[1] > 0.0);
+    c.polar = (re(ml.MU[0]) > 0.0) || (re(ml.MU[1]) > 0.0);
     if (c.polar) {
         P mm[2], sg[2], ek[2], mu2t[2];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            mm[i] = P(mtot[i]);
-            sg[i] = P(cbrt(s3sum[i] / mtot[i]));
-            ek[i] = P(eksum[i] / mtot[i]);
-            mu2t[i] = rT * (mu2sum[i] / mtot[i] * MU2_UNIT);
+            mm[i] = P(ml.M[i]);
+            sg[i] = P(d_cbrt(ml.S3[i] / ml.M[i]));
+            ek[i] = P(ml.EK[i] / ml.M[i]);
+            mu2t[i] = rT * (ml.MU[i] / ml.M[i] * MU2_UNIT);
         }
         dipole_coefficients<P>(c.pj, c.tj, mm, sg, ek, mu2t, rT);
     }
     // association (:76-86, :221-251)
-    const int associating = (ka[0] * eabs[0] != 0.0) + (ka[1] * eabs[1] != 0.0);
-    const int self_assoc = (nas[0] * nbs[0] != 0.0) + (nas[1] * nbs[1] != 0.0);
+    const int associating = (re(ml.ka[0]) * re(ml.eab[0]) != 0.0) + (re(ml.ka[1]) * re(ml.eab[1]) != 0.0);
+    const int self_assoc = (re(ml.na[0]) * re(ml.nb[0]) != 0.0) + (re(ml.na[1]) * re(ml.nb[1]) != 0.0);
     c.acls = ASSOC_NONE;
     if (associating == 1 && self_assoc == 1) c.acls = ASSOC_SELF;
     if (associating == 2 && self_assoc == 2) c.acls = ASSOC_CROSS;
     if (associating == 2 && self_assoc == 1) c.acls = ASSOC_INDUCED;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        c.na[i] = P(nas[i]);
-        c.nb[i] = P(nbs[i]);
-        c.isa[i] = sgn_d(ka[i] * eabs[i]);
+        c.na[i] = P(ml.na[i]);
+        c.nb[i] = P(ml.nb[i]);
+        c.isa[i] = sgn_d(re(ml.ka[i]) * re(ml.eab[i]));
     }
     if (c.acls == ASSOC_SELF) {  // :310-327
-        const double sg = sa[0] + sa[1], ek = ea[0] + ea[1], kap = ka[0] + ka[1], eab = eabs[0] + eabs[1];
+        Q sg = ml.sa[0] + ml.sa[1], ek = ml.ea[0] + ml.ea[1], kap = ml.ka[0] + ml.ka[1], eab = ml.eab[0] + ml.eab[1];
         P d = sg * (1.0 - 0.12 * d_exp((-3.0 * ek) * rT));
         c.dij[0] = 0.5 * d;
         c.S[0] = (sg * sg * sg * kap) * (d_exp(eab * rT) - 1.0);
     } else if (c.acls != ASSOC_NONE) {  // :334-356, :384-412
-        P d0 = sa[0] * (1.0 - 0.12 * d_exp((-3.0 * ea[0]) * rT));
-        P d1 = sa[1] * (1.0 - 0.12 * d_exp((-3.0 * ea[1]) * rT));
+        P d0 = ml.sa[0] * (1.0 - 0.12 * d_exp((-3.0 * ml.ea[0]) * rT));
+        P d1 = ml.sa[1] * (1.0 - 0.12 * d_exp((-3.0 * ml.ea[1]) * rT));
         c.dij[0] = 0.5 * d0;
         c.dij[1] = (d0 * d1) * d_recip(d0 + d1);
         c.dij[2] = 0.5 * d1;
-        const double ss = sa[0] * sa[1];
-        c.S[0] = (sa[0] * sa[0] * sa[0] * ka[0]) * (d_exp(eabs[0] * rT) - 1.0);
-        c.S[1] = (ss * sqrt(ss) * sqrt(ka[0] * ka[1])) * (d_exp((0.5 * (eabs[0] + eabs[1])) * rT) - 1.0);
-        c.S[2] = (sa[1] * sa[1] * sa[1] * ka[1]) * (d_exp(eabs[1] * rT) - 1.0);
+        Q ss = ml.sa[0] * ml.sa[1];
+        c.S[0] = (ml.sa[0] * ml.sa[0] * ml.sa[0] * ml.ka[0]) * (d_exp(ml.eab[0] * rT) - 1.0);
+        c.S[1] = (ss * d_sqrt(ss) * d_sqrt(ml.ka[0] * ml.ka[1])) * (d_exp((0.5 * (ml.eab[0] + ml.eab[1])) * rT) - 1.0);
+        c.S[2] = (ml.sa[1] * ml.sa[1] * ml.sa[1] * ml.ka[1]) * (d_exp(ml.eab[1] * rT) - 1.0);
     }
+}
+
+// row -> coefficients: T-only work done once per state point (segment diameters, packing sums, dispersion double
+// sums, bond diameters, dipole / association coefficients)
+template <class P>
+PCS_DEV void gc_coef(GcCoef<P>& c, const unsigned char* row, const GcTable& tb, double phi0, double phi1, const P& T) {
+    P rT = d_recip(T);
+    GcMol<P, double> ml;
+    gc_mol<P>(ml, c.bond_dab, c.bond_cnt, c.stride, row, tb, rT);
+    gc_finish<P, double>(c, ml, phi0, phi1, rT);
 }
 
 // gc cross association, hard-coded nA = nB = 1 (:361-374): f_i = X_i + X_i sum_j X_j D_ij - 1

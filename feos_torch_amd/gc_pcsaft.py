@@ -6,12 +6,15 @@ semantics follow the reference.  Instead of its dense ``[N,2,S]`` / ``[N,2,S,S]`
 molecule structures are encoded once into 80 bytes per row (see include/pcsaft_hip.h); identical
 molecules are encoded once and re-used.
 
-Gradients: ``k_ab`` (the tensors inside ``binary_segment_records``), ``phi`` and ``temperature``.
-k_ab and phi enter the model only through the six dispersion aggregates of a row
-(feos_torch/gc_pcsaft.py:177-194); the kernel returns dp/d(aggregates) and this module chains
-them with two [S,N]x[N,S] products.  (The reference's own d/dphi is NaN whenever the segment
-table holds a segment with epsilon_k = 0 such as '>C<' — sqrt(0) under autograd.)
-Segment-parameter gradients are not provided yet.
+Gradients: the eight segment parameter vectors, ``k_ab`` (the tensors inside ``binary_segment_records``),
+``phi`` and ``temperature`` — everything the reference's autograd reaches (feos_torch/gc_pcsaft.py:14-22,
+:54-86).  k_ab and phi enter the model only through the six dispersion aggregates of a row (:177-194);
+the kernel returns dp/d(aggregates) and this module chains them with two [S,N]x[N,S] products.  The
+segment parameters enter through 26 molecule-level sums, the dispersion double sums and the bond
+diameters; ``pcs_gc_segment_gradient`` differentiates through all of them on the device and reduces
+g_i dp_i/d(table) over the rows into one [S,8] array.  (The reference's own d/dphi and d/depsilon_k are
+NaN whenever the table holds a segment with epsilon_k = 0 such as '>C<' — sqrt(0) under autograd; here
+that one non-differentiable term is left out and everything else is finite.)
 """
 import numpy as np
 import torch
@@ -95,7 +98,7 @@ def build_table(seg, kab):
 
 class _GcBubbleDew(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dew, model, kab, phi, temperature, molefracs, pressure):
+    def forward(ctx, dew, model, kab, phi, temperature, molefracs, pressure, *segment_parameters):
         dev = model.device
         table = build_table(model.seg.to(dev), kab.detach().to(dev, torch.float64))
         ph = native._prep(phi, dev, (2,))
@@ -107,14 +110,23 @@ class _GcBubbleDew(torch.autograd.Function):
         ok = slice(None) if all_ok else ~nans
         value = r["p"][ok]
         needs = [ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]]
-        if any(needs):
+        seg_needs = list(ctx.needs_input_grad[7:])
+        if any(needs) or any(seg_needs):
             rows_ok = model.rows[ok]
             # the class order belongs to the uncompacted rows: used when every row converged
-            jac, agg = native.gc_jacobian(table, model.S, rows_ok, ph[ok], T[ok], r["rho4"][ok], dew,
-                                          order=model._class_order(table) if all_ok else None)
-            ctx.save_for_backward(jac, agg, nans.new_empty(0) if all_ok else ok, rows_ok, ph[ok], T[ok], table)
+            order = model._class_order(table) if all_ok else None
+            if any(needs):
+                jac, agg = native.gc_jacobian(table, model.S, rows_ok, ph[ok], T[ok], r["rho4"][ok], dew, order=order)
+            else:
+                jac = agg = T.new_empty(0)
+            ctx.save_for_backward(jac, agg, nans.new_empty(0) if all_ok else ok, rows_ok, ph[ok], T[ok], table,
+                                  r["rho4"][ok] if any(seg_needs) else T.new_empty(0),
+                                  order if (order is not None and any(seg_needs)) else nans.new_empty(0))
         ctx.all_ok = all_ok
         ctx.needs = needs
+        ctx.seg_needs = seg_needs
+        ctx.dew = bool(dew)
+        ctx.seg_devs = [p.device if isinstance(p, torch.Tensor) else None for p in segment_parameters]
         ctx.S = model.S
         ctx.n = T.shape[0]
         ctx.devs = (kab.device, phi.device, temperature.device)
@@ -125,7 +137,7 @@ class _GcBubbleDew(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_value, _g):
-        jac, agg, ok, rows, ph, T, table = ctx.saved_tensors
+        jac, agg, ok, rows, ph, T, table, rho4, order = ctx.saved_tensors
         if ctx.all_ok:
             ok = slice(None)
         S, n = ctx.S, ctx.n
@@ -161,7 +173,14 @@ class _GcBubbleDew(torch.autograd.Function):
             gT = torch.zeros(n, dtype=torch.float64, device=jac.device)
             gT[ok] = g * jac[:, 6]
             gT = gT.to(ctx.devs[2])
-        return None, None, gk, gphi, gT, None, None
+        gseg = [None] * len(ctx.seg_needs)
+        if any(ctx.seg_needs):
+            # the whole table in one kernel: sum_i g_i dp_i/d seg[S,8] (the segment-parameter gradient is lazy: it needs
+            # the upstream gradient, so unlike the per-row Jacobians above it runs here, not in forward)
+            G = native.gc_segment_gradient(table, S, rows, ph, T, rho4, ctx.dew, gout=g,
+                                           order=order if order.numel() == rows.shape[0] else None)
+            gseg = [G[:, k].to(ctx.seg_devs[k]) if need else None for k, need in enumerate(ctx.seg_needs)]
+        return (None, None, gk, gphi, gT, None, None, *gseg)
 
 
 class GcPcSaftMix:
@@ -169,14 +188,21 @@ class GcPcSaftMix:
         """Arguments as the reference (feos_torch/gc_pcsaft.py:14-22): segment identifiers [S], the
         8 segment parameter vectors (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb), per-row
         [segments of molecule 1, of molecule 2], per-row bond index pairs, [(s1, s2, k_ab)], phi [N,2]."""
-        if any(isinstance(p, torch.Tensor) and p.requires_grad for p in parameter):
-            raise NotImplementedError("gradients w.r.t. segment parameters are not provided yet (k_ab, phi, T are)")
+        parameter = tuple(parameter)
+        if len(parameter) != 8:
+            raise ValueError("parameter must hold the 8 segment parameter vectors (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb)")
         self.segment_identifier = list(segment_identifier)
         self.S = len(self.segment_identifier)
         if self.S > 32:
             raise ValueError("at most 32 segment types per table")
         self.device = native._dev()
-        self.seg = torch.stack([torch.as_tensor(p, dtype=torch.float64).detach().cpu() for p in parameter], dim=1).contiguous()
+        # the caller's tensors stay attached to the model: they are inputs of the autograd Function of every property
+        self._segment_parameters = tuple(p if isinstance(p, torch.Tensor) else torch.as_tensor(p, dtype=torch.float64)
+                                         for p in parameter)
+        for p in self._segment_parameters:
+            if p.dtype != torch.float64 or tuple(p.shape) != (self.S,):
+                raise ValueError(f"every segment parameter vector must be float64 of shape [{self.S}]")
+        self.seg = torch.stack([p.detach().cpu() for p in self._segment_parameters], dim=1).contiguous()
         n = len(segment_lists)
         rows = encode_rows(self.segment_identifier, segment_lists, bond_lists)
         # "Only up to one associating segment per component is allowed!" (:76-80)
@@ -210,13 +236,15 @@ class GcPcSaftMix:
 
     def bubble_point(self, temperature, liquid_molefracs, pressure):
         """(p [Pa], nans) (:470-490)."""
-        value, nans = _GcBubbleDew.apply(False, self, self.kab, self.phi, temperature, liquid_molefracs, pressure)
+        value, nans = _GcBubbleDew.apply(False, self, self.kab, self.phi, temperature, liquid_molefracs, pressure,
+                                         *self._segment_parameters)
         self.reduce(nans)
         return value, nans
 
     def dew_point(self, temperature, vapor_molefracs, pressure):
         """(p [Pa], nans) (:492-512)."""
-        value, nans = _GcBubbleDew.apply(True, self, self.kab, self.phi, temperature, vapor_molefracs, pressure)
+        value, nans = _GcBubbleDew.apply(True, self, self.kab, self.phi, temperature, vapor_molefracs, pressure,
+                                         *self._segment_parameters)
         self.reduce(nans)
         return value, nans
 

@@ -414,3 +414,24 @@ def gc_jacobian(table, S, rows, phi, temperature, rho4, dew, order=None):
                                _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_gc_jacobian")
     return jac, agg
+
+
+def gc_segment_gradient(table, S, rows, phi, temperature, rho4, dew, gout=None, order=None):
+    """[S,8] = sum_i gout[i] * d p_i / d (segment parameter table) at the converged densities rho4 (gout None = 1)."""
+    device = table.device
+    phi = _prep(phi, device, (2,))
+    temperature = _prep(temperature, device)
+    rho4 = _prep(rho4, device, (4,))
+    gout = None if gout is None else _prep(gout, device)
+    n = temperature.shape[0]
+    _check_gc(table, S, rows, n)
+    _same_rows(n, phi=phi, rho4=rho4, gout=gout)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        grad = torch.zeros((int(S), 8), dtype=_F64, device=device)
+        rc = L.pcs_gc_segment_gradient(int(bool(dew)), _lib.ptr(table), int(S), _lib.ptr(rows), _lib.ptr(phi),
+                                       _lib.ptr(temperature), _lib.ptr(rho4), n, _lib.ptr(gout), _lib.ptr(grad),
+                                       _lib.ptr(order) if order is not None and order.shape[0] == n else None,
+                                       _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_gc_segment_gradient")
+    return grad

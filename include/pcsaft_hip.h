@@ -180,6 +180,21 @@ int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const do
 int pcs_gc_jacobian(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
                     const double* rho4, int64_t n, double* jac, double* agg, const int32_t* order, void* stream);
 
+/*
+ * Gradient of the gc bubble / dew pressures [Pa] w.r.t. the SEGMENT PARAMETER TABLE, contracted with an upstream
+ * gradient over the rows — what torch reverse mode through GcPcSaftMix.bubble_point / dew_point delivers to the eight
+ * segment parameter vectors passed to the constructor (feos_torch/gc_pcsaft.py:14-22, :54-86, :470-512):
+ *   grad_seg [S,8]  +=  sum_i gout[i] * d p_i / d seg[S,8]      (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb)
+ *   gout     [n]    in   upstream gradient dL/dp_i (NULL = 1 for every row)
+ *   grad_seg [S*8]  inout ACCUMULATED with fp64 atomics: the caller zeroes it (or keeps accumulating over shards)
+ *   rho4, order     as for pcs_gc_jacobian (converged densities of the same rows; optional class order)
+ * d sqrt(eps_a eps_b) / d eps_a is taken as 0 where eps_a = 0 (the square root is not differentiable there; the
+ * reference's autograd returns NaN for every epsilon_k of such a table).
+ */
+int pcs_gc_segment_gradient(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                            const double* rho4, int64_t n, const double* gout, double* grad_seg, const int32_t* order,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,3 +298,37 @@ def gc_bubble_dew_grad(enc, phi, T, rho4, dew, s1, s2):
     lib().orc_gc_bubble_dew_grad(enc["S"], _c(enc["seg"]), _c(enc["kab"]), _c(enc["counts"]), _c(enc["bonds"]), phi, T, rho4,
                                  n, int(bool(dew)), ka, kb, val, grad)
     return val, grad
+
+
+def gc_segment_grad_fd(enc, phi, T, rho4, dew, weights=None, rel=1e-6):
+    """[S,8] central finite differences of sum_i w_i p_i (reference formula at FIXED densities rho4,
+    feos_torch/gc_pcsaft.py:470-512) w.r.t. the segment parameter table.  Entries that are structurally zero (and
+    decide the model class: kappa_ab, epsilon_k_ab, na, nb, mu = 0, epsilon_k = 0) and segments no row uses are left at
+    0.  Independent of the kernels' analytic chain: only the oracle's forward evaluation is used."""
+    phi, T, rho4 = _c(phi), _c(T), _c(rho4)
+    n = T.shape[0]
+    w = np.ones(n) if weights is None else _c(weights)
+    S = enc["S"]
+    used = enc["counts"].sum(axis=(0, 1)) > 0
+    ident = enc["ident"]
+
+    def f(seg):
+        e = dict(enc)
+        e["seg"] = seg
+        val, _ = gc_bubble_dew_grad(e, phi, T, rho4, dew, ident[0], ident[0])
+        return float((w * val).sum())
+
+    grad = np.zeros((S, 8))
+    base = _c(enc["seg"]).copy()
+    for a in range(S):
+        if not used[a]:
+            continue
+        for k in range(8):
+            if base[a, k] == 0.0:
+                continue
+            h = rel * abs(base[a, k])
+            sp, sm = base.copy(), base.copy()
+            sp[a, k] += h
+            sm[a, k] -= h
+            grad[a, k] = (f(sp) - f(sm)) / (2 * h)
+    return grad

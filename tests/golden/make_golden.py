@@ -187,3 +187,6 @@ if __name__ == "__main__":
     if "gc" in which:
         from make_golden_mix import make_gc
         make_gc(GcPcSaftMix, dump, tl)
+    if "gc_seggrad" in which or len(sys.argv) == 1:
+        from make_golden_mix import make_gc_seggrad
+        make_gc_seggrad(GcPcSaftMix, dump, tl)
