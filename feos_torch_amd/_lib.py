@@ -34,6 +34,9 @@ SIGNATURES = {
     "pcs_gc_derivatives": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "pcs_gc_jacobian": (_int, [_int, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pcs_gc_segment_gradient": (_int, [_int, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "pcs_pure_derivatives_vjp": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcs_mix_derivatives_vjp": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcs_gc_derivatives_vjp": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_mix_derivatives": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -32,6 +32,10 @@ __global__ void k_zero_ints(int32_t* __restrict__ p, int count) {
     for (int k = threadIdx.x; k < count; k += blockDim.x) p[k] = 0;
 }
 inline int zero_ints(int32_t* p, int count, hipStream_t s) {
+#ifdef PCS_ZERO_WITH_MEMSET  // A/B builds only (scripts/dev/capture_ab.py): round 1's hipMemsetAsync reset
+    hipError_t em = hipMemsetAsync(p, 0, sizeof(int32_t) * count, s);
+    return em == hipSuccess ? 0 : fail("hipMemsetAsync", em);
+#endif
     hipLaunchKernelGGL(k_zero_ints<0>, dim3(1), dim3(64), 0, s, p, count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_zero_ints launch", e);

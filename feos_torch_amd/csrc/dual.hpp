@@ -316,5 +316,11 @@ template <class T, int N> struct Lift<DN<T, N>, double> { static PCS_DEV DN<T, N
 template <class T> struct Lift<D1<T>, T> { static PCS_DEV D1<T> go(const T& p) { return D1<T>(p, T(0.0)); } };
 template <class T> struct Lift<T1<T>, T> { static PCS_DEV T1<T> go(const T& p) { return T1<T>(p, T(0.0), T(0.0)); } };
 template <class T> struct Lift<T2<T>, double> { static PCS_DEV T2<T> go(double p) { return T2<T>(p); } };
+template <class T, int N> struct Lift<T2<DN<T, N>>, DN<T, N>> {
+    static PCS_DEV T2<DN<T, N>> go(const DN<T, N>& p) { const DN<T, N> z(0.0); return T2<DN<T, N>>(p, z, z, z, z, z); }
+};
+template <class T, int N> struct Lift<D2<DN<T, N>>, DN<T, N>> {
+    static PCS_DEV D2<DN<T, N>> go(const DN<T, N>& p) { const DN<T, N> z(0.0); return D2<DN<T, N>>(p, z, z); }
+};
 
 }  // namespace pcs

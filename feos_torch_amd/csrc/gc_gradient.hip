@@ -15,7 +15,12 @@
 //   3. the chain from the sums to the parameters of the <= 8 segment types of each molecule is a few multiply-adds per
 //      entry; g_i * dp_i/dtheta is accumulated over the rows of a workgroup in an LDS copy of the [S,8] table
 //      (ds_add_f64) and flushed once per workgroup with global fp64 atomics (persistent grid: 2048 flushes per call).
-// Only the table gradient is produced here; k_ab, phi and T are pcs_gc_jacobian's.
+// For the bubble / dew pressures only the table gradient is produced here; k_ab, phi and T are pcs_gc_jacobian's.
+//
+// The same machinery serves the vector-Jacobian product of GcPcSaftMix.derivatives / helmholtz_energy_density
+// (feos_torch/gc_pcsaft.py:443-468; MODE 1): there the functional is L = ga a + gp p + gmu . mu + gv . v at ONE density
+// point, linear in the six Taylor coefficients of a (DerivWeights, mix_jacobian.hpp), so the probes are T2<DN> / T2<double>
+// instead of D1 along beta, and the kernel also returns the per-row dL/d(6 aggregates, T, rho_0, rho_1).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,12 +29,15 @@
 #include "gc_model.hpp"
 #include "gc_kernel_common.hpp"
 #include "mix_solver.hpp"
+#include "mix_jacobian.hpp"  // DerivWeights
 
 namespace {
 
 constexpr int GSBLOCK = 64;
 constexpr int GS_GRID = 2048;
-constexpr int GS_CHUNK = 2;  // slot j of a pass = molecule j
+// dual-number directions per pass.  MODE 0 (D1 probes): one molecule-level quantity of BOTH molecules (slot j = molecule j);
+// MODE 1 (T2 probes, three times the state per value): one molecule per pass -- with two the stack frame is 4.4 KB per lane
+template <int MODE> struct GsChunk { static constexpr int value = MODE == 0 ? 2 : 1; };
 
 enum : int { Q_M, Q_Z1, Q_Z2, Q_Z3, Q_S3, Q_EK, Q_MU, Q_SA, Q_EA, Q_KA, Q_EAB, Q_NA, Q_NB, Q_COUNT };
 
@@ -44,15 +52,16 @@ __device__ __forceinline__ void diameter_grad(const double* seg, double rT, doub
     d_eps = seg[1] * (0.36 * rT) * ex;
 }
 
-// coefficients with the tangents of molecule-level quantity q (slot j: molecule j); out of line as mix_coef_tangent
-template <class G>
-__device__ __attribute__((noinline)) void gc_finish_tangent(GcCoef<G>& c, const GcMol<double, double>& ml, int q, double phi0,
-                                                            double phi1, double rT) {
+// coefficients with the tangents of molecule-level quantity q; out of line as mix_coef_tangent.  CH = 2: slot j = molecule
+// j; CH = 1: slot 0 = molecule jm
+template <class G, int CH>
+__device__ __attribute__((noinline)) void gc_finish_tangent(GcCoef<G>& c, const GcMol<double, double>& ml, int q, int jm,
+                                                            double phi0, double phi1, double rT) {
     GcMol<G, G> g;
 #define PCS_SEED(field, code)                                   \
     _Pragma("unroll") for (int i = 0; i < 2; i++) {             \
         g.field[i] = G(ml.field[i]);                            \
-        if (q == code) g.field[i].e[i] = 1.0;                   \
+        if (q == code && (CH == 2 || i == jm)) g.field[i].e[CH == 2 ? i : 0] = 1.0; \
     }
     PCS_SEED(M, Q_M)
     PCS_SEED(S3, Q_S3)
@@ -70,7 +79,7 @@ __device__ __attribute__((noinline)) void gc_finish_tangent(GcCoef<G>& c, const 
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             g.Zk[k][i] = G(ml.Zk[k][i]);
-            if (q == Q_Z1 + k) g.Zk[k][i].e[i] = 1.0;
+            if (q == Q_Z1 + k && (CH == 2 || i == jm)) g.Zk[k][i].e[CH == 2 ? i : 0] = 1.0;
         }
         g.s1[k] = G(ml.s1[k]);
         g.s2[k] = G(ml.s2[k]);
@@ -78,17 +87,40 @@ __device__ __attribute__((noinline)) void gc_finish_tangent(GcCoef<G>& c, const 
     gc_finish<G, G>(c, g, phi0, phi1, G(rT));
 }
 
-__global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(int dew, const double* __restrict__ table, int S,
-                                                                 const unsigned char* __restrict__ rows,
-                                                                 const double* __restrict__ phi,
-                                                                 const double* __restrict__ temp,
-                                                                 const double* __restrict__ rho4, int64_t n,
-                                                                 const double* __restrict__ gout,
-                                                                 double* __restrict__ grad_seg,
-                                                                 const int32_t* __restrict__ order) {
-    typedef DN<double, GS_CHUNK> G;
-    typedef D1<G> R;
-    typedef D1<double> Q1;
+// the functional whose table gradient is taken: MODE 0 = bubble / dew pressure (two phases, D1 probes along beta),
+// MODE 1 = L = ga a + gp p + gmu . mu + gv . v of `derivatives` (one point, T2 probes)
+template <int MODE, class X> struct ProbeT { typedef D1<X> type; };
+template <class X> struct ProbeT<1, X> { typedef T2<X> type; };
+
+struct GcGradArgs {
+    int dew;
+    const double* table; int S; const unsigned char* rows; const double* phi; const double* temp;
+    const double* rho;   // MODE 0: rho4 [n,4], MODE 1: rho [n,2]
+    int64_t n;
+    const double* gout;  // MODE 0: upstream dL/dp [n] or NULL
+    const double *g_a, *g_p, *g_mu, *g_v;  // MODE 1: upstream gradients (each may be NULL)
+    double* grad_seg;    // [S,8] accumulated
+    double* jac9;        // MODE 1: [n,9] dL/d(A00, A01, A11, B00, B01, B11, T, rho_0, rho_1)
+    double* agg;         // MODE 1: [n,6] aggregate values (optional)
+    const int32_t* order;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArgs A_) {
+    const int dew = A_.dew, S = A_.S;
+    const double* __restrict__ table = A_.table;
+    const unsigned char* __restrict__ rows = A_.rows;
+    const double* __restrict__ phi = A_.phi;
+    const double* __restrict__ temp = A_.temp;
+    const int64_t n = A_.n;
+    const double* __restrict__ gout = A_.gout;
+    double* __restrict__ grad_seg = A_.grad_seg;
+    const int32_t* __restrict__ order = A_.order;
+    constexpr int NPT = MODE == 0 ? 2 : 1;
+    constexpr int CH = GsChunk<MODE>::value;
+    typedef DN<double, CH> G;
+    typedef typename ProbeT<MODE, G>::type R;
+    typedef typename ProbeT<MODE, double>::type Q1;
     extern __shared__ double lds[];
     GcTable tb = stage_table(table, S, lds);
     double* acc = lds + gc_table_doubles(S);                          // [S][8] gradient of this workgroup
@@ -115,17 +147,24 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(int dew, const 
         const unsigned char* row = rows + (size_t)i * GC_ROW_BYTES;
         const double T = temp[i], ph0 = phi[2 * i], ph1 = phi[2 * i + 1];
         const double rT = 1.0 / T;
-        const double4 r4 = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
-        const double s0 = dew ? r4.x : r4.z, s1 = dew ? r4.y : r4.w, i0 = dew ? r4.z : r4.x, i1 = dew ? r4.w : r4.y;
+        // density points of the functional: pt 0 = specified phase (MODE 0) or the state point (MODE 1), pt 1 = incipient phase
+        double s0, s1, i0, i1;
+        if (MODE == 0) {
+            const double4 r4 = reinterpret_cast<const double4*>(A_.rho)[i];  // (V0, V1, L0, L1)
+            s0 = dew ? r4.x : r4.z; s1 = dew ? r4.y : r4.w; i0 = dew ? r4.z : r4.x; i1 = dew ? r4.w : r4.y;
+        } else {
+            s0 = i0 = A_.rho[2 * i]; s1 = i1 = A_.rho[2 * i + 1];
+        }
 
         GcMol<double, double> ml;
         gc_mol<double>(ml, m.c.bond_dab, m.c.bond_cnt, m.c.stride, row, tb, rT);
         gc_finish<double, double>(m.c, ml, ph0, ph1, rT);
 
-        // adjoint of the converged state (mix_jacobian.hpp): J^T w = dp^vap/du
         double alpha[2], beta0[2], beta1[2];
-        bool ok;
-        {
+        DerivWeights dw;
+        bool ok = true;
+        if (MODE == 0) {
+            // adjoint of the converged state (mix_jacobian.hpp): J^T w = dp^vap/du
             PhaseEval s = phase_eval(m, s0, s1);
             PhaseEval nn = phase_eval(m, i0, i1);
             const double rs = s0 + s1, z0 = s0 / rs, z1 = s1 / rs;
@@ -163,10 +202,34 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(int dew, const 
                 alpha[0] = w[2];   beta0[0] = -w[2] * s0 - w[0]; beta1[0] = -w[2] * s1 - w[1];
                 alpha[1] = -u;     beta0[1] = u * i0 + w[0];     beta1[1] = u * i1 + w[1];
             }
+        } else {
+            const PhaseEval e = phase_eval(m, s0, s1);
+            dw = deriv_weights(e, A_.g_a ? A_.g_a[i] : 0.0, A_.g_p ? A_.g_p[i] : 0.0, A_.g_mu ? A_.g_mu[2 * i] : 0.0,
+                               A_.g_mu ? A_.g_mu[2 * i + 1] : 0.0, A_.g_v ? A_.g_v[2 * i] : 0.0, A_.g_v ? A_.g_v[2 * i + 1] : 0.0);
+            alpha[0] = alpha[1] = beta0[0] = beta0[1] = beta1[0] = beta1[1] = 0.0;
         }
+        // the two probe flavours: seeds of the density arguments and the contraction of a result with the row's weights
+        auto seed0 = [&](int pt, auto zero) {
+            typedef decltype(zero) X;
+            if constexpr (MODE == 0) return D1<X>(X(pt == 0 ? s0 : i0), X(pt == 0 ? beta0[0] : beta0[1]));
+            else return T2<X>(X(s0), X(1.0), X(0.0), X(0.0), X(0.0), X(0.0));
+        };
+        auto seed1 = [&](int pt, auto zero) {
+            typedef decltype(zero) X;
+            if constexpr (MODE == 0) return D1<X>(X(pt == 0 ? s1 : i1), X(pt == 0 ? beta1[0] : beta1[1]));
+            else return T2<X>(X(s1), X(0.0), X(1.0), X(0.0), X(0.0), X(0.0));
+        };
+        auto dot_g = [&](const R& a, int pt, int j) -> double {
+            if constexpr (MODE == 0) return (pt == 0 ? alpha[0] : alpha[1]) * a.v.e[j] + a.d1.e[j];
+            else return deriv_contract(dw, a, j);
+        };
+        auto dot_q = [&](const Q1& a, int pt) -> double {
+            if constexpr (MODE == 0) return (pt == 0 ? alpha[0] : alpha[1]) * a.v + a.d1;
+            else return dw.cv * a.v + dw.cg0 * a.g0 + dw.cg1 * a.g1 + dw.ch00 * a.h00 + dw.ch01 * a.h01 + dw.ch11 * a.h11;
+        };
         // weight of this row: upstream gradient x (reduced -> Pa); a singular adjoint poisons the result like the
         // per-row NaN of pcs_gc_jacobian
-        const double wrow = ok ? (gout ? gout[i] : 1.0) * (T * P_UNIT) : nanv;
+        const double wrow = MODE == 0 ? (ok ? (gout ? gout[i] : 1.0) * (T * P_UNIT) : nanv) : 1.0;
 
         // ---- (1) molecule-level sums: dual-number passes -------------------------------------------------------
         {
@@ -175,27 +238,32 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(int dew, const 
             for (int e = 0; e < 2 * GC_MAXE; e++) gbonds[threadIdx.x + e * GSBLOCK] = G(m.c.bond_dab[e * GSBLOCK]);
             const bool polar = m.c.polar, assoc = m.c.acls != ASSOC_NONE;
 #pragma unroll 1
-            for (int q = 0; q < Q_COUNT; q++) {
+            for (int qq = 0; qq < Q_COUNT * (3 - CH); qq++) {
+                const int q = CH == 2 ? qq : qq >> 1, jm = CH == 2 ? 0 : qq & 1;
                 const bool need = (q <= Q_Z3) || (q <= Q_MU ? polar : assoc);
                 if (__ballot(need) == 0ull) continue;  // the whole wave skips the pass
                 GcCoef<G> c;
                 c.bond_dab = gbonds + threadIdx.x;
                 c.bond_cnt = m.c.bond_cnt;
                 c.stride = GSBLOCK;
-                gc_finish_tangent<G>(c, ml, q, ph0, ph1, rT);
+                gc_finish_tangent<G, CH>(c, ml, q, jm, ph0, ph1, rT);
                 double val[2] = {0.0, 0.0};
 #pragma unroll 1
-                for (int ph = 0; ph < 2; ph++) {
-                    const double q0 = ph == 0 ? s0 : i0, q1 = ph == 0 ? s1 : i1;
-                    const double al = ph == 0 ? alpha[0] : alpha[1], b0 = ph == 0 ? beta0[0] : beta0[1], b1 = ph == 0 ? beta1[0] : beta1[1];
-                    R a = gc_a_tangent<G, R>(c, R(G(q0), G(b0)), R(G(q1), G(b1)));
+                for (int pt = 0; pt < NPT; pt++) {
+                    R a = gc_a_tangent<G, R>(c, seed0(pt, G(0.0)), seed1(pt, G(0.0)));
+                    if (CH == 2) {
 #pragma unroll
-                    for (int j = 0; j < 2; j++) val[j] += al * a.v.e[j] + a.d1.e[j];
+                        for (int j = 0; j < 2; j++) val[j] += dot_g(a, pt, j < CH ? j : 0);
+                    } else {
+                        const double v = dot_g(a, pt, 0);
+                        if (jm == 0) val[0] += v; else val[1] += v;
+                    }
                 }
                 if (!need) continue;
                 // chain to the segment parameters of molecule j's entries
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
+                    if (CH == 1 && j != jm) continue;
                     const double gq = wrow * val[j];
 #pragma unroll 1
                     for (int e = 0; e < GC_MAXE; e++) {
@@ -236,30 +304,62 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(int dew, const 
             }
         }
 
-        // ---- (2) dispersion double sums and (3) bond diameters: closed forms in D1<double> along beta ------------
+        // ---- MODE 1 only: the per-row directions T, rho_0, rho_1 (T through the full coefficient set-up) -------------
+        if constexpr (MODE == 1) {
+            double* g9 = A_.jac9 + 9 * i;
+            GcCoef<G> c;
+            c.bond_dab = gbonds + threadIdx.x;
+            c.bond_cnt = m.c.bond_cnt;  // counts are rewritten identically
+            c.stride = GSBLOCK;
+#pragma unroll 1
+            for (int pass = 0; pass < 3; pass++) {  // T (through the full coefficient set-up), rho_0, rho_1
+                if (pass < 2) {
+                    G gT(T);
+                    if (pass == 0) gT.e[0] = 1.0;
+                    gc_coef<G>(c, row, tb, ph0, ph1, gT);
+                }
+                G q0(s0), q1(s1);
+                if (pass == 1) q0.e[0] = 1.0;
+                if (pass == 2) q1.e[0] = 1.0;
+                const G one(1.0), nul(0.0);
+                R a = gc_a_tangent<G, R>(c, R(q0, one, nul, nul, nul, nul), R(q1, nul, one, nul, nul, nul));
+                const double v = deriv_contract(dw, a, 0);
+                if (pass == 0) g9[6] = v;
+                else if (pass == 1) g9[7] = v + dw.x0;
+                else g9[8] = v + dw.x1;
+            }
+        }
+
+        // ---- (2) dispersion double sums and (3) bond diameters: closed forms in the probe type over double ----------
         double gA[3] = {0.0, 0.0, 0.0}, gB[3] = {0.0, 0.0, 0.0};
-        Q1 pcc[2], pz3m1[2], pomz[2], pr[2][2];
+        Q1 pcc[NPT], pz3m1[NPT], pomz[NPT], pr[NPT][2];
 #pragma unroll
-        for (int ph = 0; ph < 2; ph++) {
-            const double al = alpha[ph];
-            const Q1 r0(ph == 0 ? s0 : i0, beta0[ph]), r1(ph == 0 ? s1 : i1, beta1[ph]);
+        for (int pt = 0; pt < NPT; pt++) {
+            const Q1 r0 = seed0(pt, 0.0), r1 = seed1(pt, 0.0);
             Q1 F1, F2;
             dispersion_factors(m.c, r0, r1, F1, F2);
             const Q1 q[3] = {r0 * r0, r0 * r1, r1 * r1};
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                Q1 t = F1 * q[k];
-                gA[k] += al * t.v + t.d1;
-                t = F2 * q[k];
-                gB[k] += al * t.v + t.d1;
+                gA[k] += dot_q(F1 * q[k], pt);
+                gB[k] += dot_q(F2 * q[k], pt);
             }
             const Q1 zeta2 = r0 * m.c.zk[2][0] + r1 * m.c.zk[2][1];
             const Q1 zeta3 = r0 * m.c.zk[3][0] + r1 * m.c.zk[3][1];
-            pomz[ph] = 1.0 - zeta3;
-            pz3m1[ph] = d_recip(pomz[ph]);
-            pcc[ph] = zeta2 * (pz3m1[ph] * pz3m1[ph]);
-            pr[ph][0] = r0;
-            pr[ph][1] = r1;
+            pomz[pt] = 1.0 - zeta3;
+            pz3m1[pt] = d_recip(pomz[pt]);
+            pcc[pt] = zeta2 * (pz3m1[pt] * pz3m1[pt]);
+            pr[pt][0] = r0;
+            pr[pt][1] = r1;
+        }
+        if (MODE == 1) {
+            double* g9 = A_.jac9 + 9 * i;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { g9[k] = gA[k]; g9[3 + k] = gB[k]; }
+            if (A_.agg) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { A_.agg[6 * i + k] = m.c.A[k]; A_.agg[6 * i + 3 + k] = m.c.B[k]; }
+            }
         }
         {
             // A[pr] = rT (phi-factor) s1[pr], B[pr] = rT^2 (phi-factor)^2 s2[pr]  (gc_finish)
@@ -316,11 +416,11 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(int dew, const 
                 const double dab = m.c.bond_dab[slot];
                 double gd = 0.0;
 #pragma unroll
-                for (int ph = 0; ph < 2; ph++) {
-                    const Q1 cd = pcc[ph] * dab;
-                    const Q1 g = pz3m1[ph] + 3.0 * cd + 2.0 * ((cd * cd) * pomz[ph]);
-                    const Q1 x = (pr[ph][mi] * (-cnt)) * ((pcc[ph] * (3.0 + 4.0 * (cd * pomz[ph]))) * d_recip(g));
-                    gd += alpha[ph] * x.v + x.d1;
+                for (int pt = 0; pt < NPT; pt++) {
+                    const Q1 cd = pcc[pt] * dab;
+                    const Q1 g = pz3m1[pt] + 3.0 * cd + 2.0 * ((cd * cd) * pomz[pt]);
+                    const Q1 x = (pr[pt][mi] * (-cnt)) * ((pcc[pt] * (3.0 + 4.0 * (cd * pomz[pt]))) * d_recip(g));
+                    gd += dot_q(x, pt);
                 }
                 gd *= wrow;
                 const int a = row[32 + mi * GC_MAXE + e], b = row[48 + mi * GC_MAXE + e];
@@ -347,6 +447,18 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(int dew, const 
 
 extern "C" {
 
+static int launch_gc_gradient(int mode, const GcGradArgs& a, void* stream, const char* what) {
+    const int64_t tiles = (a.n + GSBLOCK - 1) / GSBLOCK;
+    const unsigned grid = (unsigned)(tiles < GS_GRID ? tiles : GS_GRID);
+    // table + gradient accumulator + per thread: double model 4*MAXE doubles, dual model dab 2*MAXE*(1+CHUNK)
+    const size_t lds = gc_lds_bytes(a.S, GSBLOCK, 4 * GC_MAXE + 2 * GC_MAXE * (1 + 2)) + sizeof(double) * a.S * 8;
+    if (mode == 0) hipLaunchKernelGGL(k_gc_segment_gradient<0>, dim3(grid), dim3(GSBLOCK), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL(k_gc_segment_gradient<1>, dim3(grid), dim3(GSBLOCK), lds, as_stream(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(what, e);
+    return 0;
+}
+
 int pcs_gc_segment_gradient(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
                             const double* rho4, int64_t n, const double* gout, double* grad_seg, const int32_t* order,
                             void* stream) {
@@ -354,15 +466,23 @@ int pcs_gc_segment_gradient(int dew, const double* table, int S, const uint8_t* 
     if (int e = gc_check(S, n)) return e;
     if (n == 0) return 0;
     if (!table || !rows || !phi || !temp || !rho4 || !grad_seg) return fail_msg("pcs_gc_segment_gradient: null required pointer");
-    const int64_t tiles = (n + GSBLOCK - 1) / GSBLOCK;
-    const unsigned grid = (unsigned)(tiles < GS_GRID ? tiles : GS_GRID);
-    // table + gradient accumulator + per thread: double model 4*MAXE doubles, dual model dab 2*MAXE*(1+CHUNK)
-    const size_t lds = gc_lds_bytes(S, GSBLOCK, 4 * GC_MAXE + 2 * GC_MAXE * (1 + GS_CHUNK)) + sizeof(double) * S * 8;
-    hipLaunchKernelGGL(k_gc_segment_gradient, dim3(grid), dim3(GSBLOCK), lds, as_stream(stream), dew, table, S, rows, phi,
-                       temp, rho4, n, gout, grad_seg, order);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail("k_gc_segment_gradient launch", e);
-    return 0;
+    GcGradArgs a{};
+    a.dew = dew; a.table = table; a.S = S; a.rows = rows; a.phi = phi; a.temp = temp; a.rho = rho4; a.n = n;
+    a.gout = gout; a.grad_seg = grad_seg; a.order = order;
+    return launch_gc_gradient(0, a, stream, "k_gc_segment_gradient launch");
+}
+
+int pcs_gc_derivatives_vjp(const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                           const double* rho, int64_t n, const double* g_a, const double* g_p, const double* g_mu,
+                           const double* g_v, double* grad_seg, double* jac9, double* agg, const int32_t* order, void* stream) {
+    g_err[0] = 0;
+    if (int e = gc_check(S, n)) return e;
+    if (n == 0) return 0;
+    if (!table || !rows || !phi || !temp || !rho || !grad_seg || !jac9) return fail_msg("pcs_gc_derivatives_vjp: null required pointer");
+    GcGradArgs a{};
+    a.table = table; a.S = S; a.rows = rows; a.phi = phi; a.temp = temp; a.rho = rho; a.n = n;
+    a.g_a = g_a; a.g_p = g_p; a.g_mu = g_mu; a.g_v = g_v; a.grad_seg = grad_seg; a.jac9 = jac9; a.agg = agg; a.order = order;
+    return launch_gc_gradient(1, a, stream, "k_gc_derivatives_vjp launch");
 }
 
 }  // extern "C"

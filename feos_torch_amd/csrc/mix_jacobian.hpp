@@ -187,4 +187,90 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Vector-Jacobian product of PcSaftMix.derivatives / GcPcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420):
+//   a,  p = r0 + r1 - a + r0 a_0 + r1 a_1,  mu_i = a_i,  v_i = d_i / (r0 d0 + r1 d1),  d_i = 1 + r0 a_i0 + r1 a_i1
+// (a_i, a_ij: density derivatives of a).  In the reference these are torch graphs, so a loss built on them reaches
+// parameters, temperature and the densities.  With upstream gradients (ga, gp, gmu[2], gv[2]) the loss is, to first
+// order, linear in the six Taylor coefficients of a: dL = sum_k c_k d(coef_k); DerivWeights holds the c_k, the explicit
+// density terms and v.  Any forward-mode evaluation R = T2<DN> then gives dL/dtheta = sum_k c_k coef_k.e.
+// ------------------------------------------------------------------------------------------------------------------
+struct DerivWeights {
+    double cv, cg0, cg1, ch00, ch01, ch11;  // dL/d(a, a_0, a_1, a_00, a_01, a_11)
+    double x0, x1;                          // explicit dL/dr0, dL/dr1 at fixed Taylor coefficients
+};
+PCS_DEV DerivWeights deriv_weights(const PhaseEval& e, double ga, double gp, double gm0, double gm1, double gv0, double gv1) {
+    DerivWeights w;
+    const double d0 = e.dp0(), d1 = e.dp1();
+    const double rD = 1.0 / (e.r0 * d0 + e.r1 * d1);
+    const double Sv = (gv0 * d0 + gv1 * d1) * rD;  // sum gv_i v_i
+    const double e0 = (gv0 - Sv * e.r0) * rD, e1 = (gv1 - Sv * e.r1) * rD;  // dL/dd_j
+    w.cv = ga - gp;
+    w.cg0 = gp * e.r0 + gm0;
+    w.cg1 = gp * e.r1 + gm1;
+    w.ch00 = e0 * e.r0;
+    w.ch01 = e0 * e.r1 + e1 * e.r0;
+    w.ch11 = e1 * e.r1;
+    w.x0 = gp * (1.0 + e.g0) + e0 * e.h00 + e1 * e.h01 - Sv * d0 * rD;
+    w.x1 = gp * (1.0 + e.g1) + e0 * e.h01 + e1 * e.h11 - Sv * d1 * rD;
+    return w;
+}
+template <class G>
+PCS_DEV double deriv_contract(const DerivWeights& w, const T2<G>& a, int j) {
+    return w.cv * a.v.e[j] + w.cg0 * a.g0.e[j] + w.cg1 * a.g1.e[j] + w.ch00 * a.h00.e[j] + w.ch01 * a.h01.e[j] + w.ch11 * a.h11.e[j];
+}
+
+constexpr int MIX_VJP_DIRS = 21;  // 16 parameters, k_ij, eps_AiBj, T, rho_0, rho_1
+
+// coefficients with the tangent of ONE direction d (0..18 as MIX_DIRS); out of line like mix_coef_tangent
+template <class G>
+__device__ __attribute__((noinline)) void mix_coef_direction(MixCoef<G>& c, const double* __restrict__ par, double k0, double k1, double T, int d) {
+    G gp[16], gk0, gk1, gT;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        gp[k].v = par[k];
+        gp[k].e[0] = (d == k) ? 1.0 : 0.0;
+    }
+    gk0.v = k0; gk1.v = k1; gT.v = T;
+    gk0.e[0] = (d == 16) ? 1.0 : 0.0;
+    gk1.e[0] = (d == 17) ? 1.0 : 0.0;
+    gT.e[0] = (d == 18) ? 1.0 : 0.0;
+    mix_coef<G>(c, gp, gk0, gk1, gT);
+}
+
+// out[21] = dL/d(params[0,0..7], params[1,0..7], kij0, kij1, T, rho_0, rho_1)
+PCS_DEV void mix_derivatives_vjp(const double par[16], double k0, double k1, double T, double r0, double r1, double ga,
+                                 double gp, double gm0, double gm1, double gv0, double gv1, double* __restrict__ g) {
+    typedef DN<double, 1> G;
+    typedef T2<G> R;
+    MixModelD m;
+    mix_coef<double>(m.c, par, k0, k1, T);
+    const PhaseEval e = phase_eval(m, r0, r1);
+    const DerivWeights w = deriv_weights(e, ga, gp, gm0, gm1, gv0, gv1);
+    const bool no_assoc = m.c.acls == ASSOC_NONE;
+    const bool eab_used = m.c.acls == ASSOC_CROSS && k1 != 0.0;
+#pragma unroll 1
+    for (int d = 0; d < MIX_VJP_DIRS; d++) {
+        bool zero = false;  // structurally-zero directions (see mix_jacobian)
+        const int kk = d & 7;
+        if (d < 16) zero = (kk == 3 && par[d] == 0.0) || (kk >= 4 && no_assoc);
+        else if (d == 17) zero = !eab_used;
+        if (__ballot(!zero) == 0ull) {
+            g[d] = 0.0;
+            continue;
+        }
+        MixCoef<G> c;
+        mix_coef_direction<G>(c, par, k0, k1, T, d < 19 ? d : -1);
+        G q0(r0), q1(r1);
+        if (d == 19) q0.e[0] = 1.0;
+        if (d == 20) q1.e[0] = 1.0;
+        const G one(1.0), nul(0.0);
+        R a = mix_a_tangent<G, R>(c, R(q0, one, nul, nul, nul, nul), R(q1, nul, one, nul, nul, nul));
+        double val = deriv_contract(w, a, 0);
+        if (d == 19) val += w.x0;
+        if (d == 20) val += w.x1;
+        g[d] = zero ? 0.0 : val;
+    }
+}
+
 }  // namespace pcs

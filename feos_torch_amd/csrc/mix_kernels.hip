@@ -419,6 +419,26 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* 
     else mix_jacobian(par, k0, k1, temp[i], r.z, r.w, r.x, r.y, false, g);
 }
 
+// vector-Jacobian product of PcSaftMix.derivatives (autograd of derivatives / helmholtz_energy_density)
+__global__ __launch_bounds__(64) void k_mix_derivatives_vjp(const double* __restrict__ params, const double* __restrict__ kij,
+                                                            const double* __restrict__ temp, const double* __restrict__ rho,
+                                                            int64_t n, const double* __restrict__ g_a,
+                                                            const double* __restrict__ g_p, const double* __restrict__ g_mu,
+                                                            const double* __restrict__ g_v, double* __restrict__ grad,
+                                                            const int32_t* __restrict__ order) {
+    int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    if (order) {  // class order (k_mix_class_*): class-uniform waves skip the structurally-zero directions
+        i = order[i];
+        if (i < 0 || i >= n) return;
+    }
+    double par[16], k0, k1;
+    load_mix_row(params, kij, i, par, k0, k1);
+    mix_derivatives_vjp(par, k0, k1, temp[i], rho[2 * i], rho[2 * i + 1], g_a ? g_a[i] : 0.0, g_p ? g_p[i] : 0.0,
+                        g_mu ? g_mu[2 * i] : 0.0, g_mu ? g_mu[2 * i + 1] : 0.0, g_v ? g_v[2 * i] : 0.0, g_v ? g_v[2 * i + 1] : 0.0,
+                        grad + MIX_VJP_DIRS * i);
+}
+
 // resident waves of the queue kernel: one per SIMD (the evaluation needs the whole register file)
 int queue_waves() {
     static int waves = 0;
@@ -502,6 +522,32 @@ int pcs_mix_derivatives(const double* params, const double* kij, const double* t
                        temp, rho, n, a, p, mu, v);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_mix_derivatives launch", e);
+    return 0;
+}
+
+int pcs_mix_derivatives_vjp(const double* params, const double* kij, const double* temp, const double* rho, int64_t n,
+                            const double* g_a, const double* g_p, const double* g_mu, const double* g_v, double* grad,
+                            void* workspace, void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !kij || !temp || !rho || !grad) return fail_msg("pcs_mix_derivatives_vjp: null required pointer");
+    hipStream_t s = as_stream(stream);
+    const int32_t* order = nullptr;
+    if (workspace) {
+        int32_t* perm = static_cast<int32_t*>(workspace);
+        int32_t* ctrl = perm + n;
+        if (int ez = zero_ints(ctrl, QCTRL_INTS, s)) return ez;
+        const unsigned g256 = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);
+        hipLaunchKernelGGL(k_mix_class_scan, dim3(1), dim3(64), 0, s, ctrl);
+        hipLaunchKernelGGL(k_mix_class_scatter, dim3(g256), dim3(256), 0, s, params, n, ctrl, perm);
+        order = perm;
+    }
+    hipLaunchKernelGGL(k_mix_derivatives_vjp, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, params, kij, temp, rho, n, g_a,
+                       g_p, g_mu, g_v, grad, order);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_mix_derivatives_vjp launch", e);
     return 0;
 }
 

@@ -87,4 +87,46 @@ PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv
     }
 }
 
+// Vector-Jacobian product of PcSaftPure.derivatives (feos_torch/pcsaft_pure.py:180-182): the outputs
+//   a,  p = rho - a + rho a1,  dp = 1 + rho a2        (a1, a2, a3: density derivatives of a)
+// are plain torch graphs in the reference, so a loss built on them back-propagates to parameters, temperature AND
+// density.  Given the upstream gradients (ga, gp, gdp) this returns dL/d(8 parameters, T, rho) with
+// L = ga a + gp p + gdp dp: D2<DN> evaluations (a, a1, a2 with tangents), JAC_CHUNK directions per pass; the density is
+// the tenth direction (its tangent of a2 is a3) plus the explicit terms gp (1 + a1) + gdp a2.
+constexpr int VJP_DIRS = 10;  // 8 parameters, T, rho
+PCS_DEV void pure_derivatives_vjp(const double par[8], double T, double rho, double ga, double gp, double gdp, double g[VJP_DIRS]) {
+    typedef DN<double, JAC_CHUNK> G;
+    typedef D2<G> R;
+    constexpr int NPASS = (VJP_DIRS + JAC_CHUNK - 1) / JAC_CHUNK;
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; pass++) {
+        const int d0 = pass * JAC_CHUNK;
+        G gp_[8], gT, gR;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            gp_[k].v = par[k];
+#pragma unroll
+            for (int j = 0; j < JAC_CHUNK; j++) gp_[k].e[j] = (d0 + j == k) ? 1.0 : 0.0;
+        }
+        gT.v = T;
+        gR.v = rho;
+#pragma unroll
+        for (int j = 0; j < JAC_CHUNK; j++) {
+            gT.e[j] = (d0 + j == 8) ? 1.0 : 0.0;
+            gR.e[j] = (d0 + j == 9) ? 1.0 : 0.0;
+        }
+        PureCoef<G> c;
+        pure_coef<G>(c, gp_, gT, true);
+        R a = pure_a<G, R>(c, R(gR, G(1.0), G(0.0)));
+#pragma unroll
+        for (int j = 0; j < JAC_CHUNK; j++) {
+            double val = (ga - gp) * a.v.e[j] + (gp * rho) * a.d1.e[j] + (gdp * rho) * a.d2.e[j];
+            if (d0 + j == 9) val += gp * (1.0 + a.d1.v) + gdp * a.d2.v;  // explicit density dependence of p and dp
+#pragma unroll
+            for (int d = 0; d < VJP_DIRS; d++)
+                if (d == d0 + j) g[d] = val;
+        }
+    }
+}
+
 }  // namespace pcs

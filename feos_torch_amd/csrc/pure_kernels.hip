@@ -349,11 +349,39 @@ __global__ __launch_bounds__(BLOCK) void k_pure_jacobian(const double* __restric
     for (int k = 0; k < 10; k++) jac[10 * i + k] = g[k];
 }
 
+// ------------------------------------------------------------------------------------------
+// vector-Jacobian product of (a, p, dp) w.r.t. (8 parameters, T, rho): autograd of PcSaftPure.derivatives / helmholtz_energy
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pure_derivatives_vjp(const double* __restrict__ params,
+                                                                const double* __restrict__ temp,
+                                                                const double* __restrict__ rho_in, int64_t n,
+                                                                const double* __restrict__ g_a, const double* __restrict__ g_p,
+                                                                const double* __restrict__ g_dp,
+                                                                double* __restrict__ grad_params, double* __restrict__ grad_temp,
+                                                                double* __restrict__ grad_rho) {
+    __shared__ double lds[BLOCK * ROW_PAD];
+    const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = row0 + threadIdx.x;
+    const bool live = i < n;
+    double par[8];
+    stage_params(params, n, row0, lds, par);
+    const int64_t ii = live ? i : n - 1;
+    double g[VJP_DIRS];
+    pure_derivatives_vjp(par, temp[ii], rho_in[ii], g_a ? g_a[ii] : 0.0, g_p ? g_p[ii] : 0.0, g_dp ? g_dp[ii] : 0.0, g);
+    if (!live) return;
+    if (grad_params) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) grad_params[8 * i + k] = g[k];
+    }
+    if (grad_temp) grad_temp[i] = g[8];
+    if (grad_rho) grad_rho[i] = g[9];
+}
+
 }  // namespace
 
 extern "C" {
 
-int pcs_abi_version(void) { return 101; }  // 101: workspace on pcs_mix_jacobian, row order on pcs_gc_bubble_dew / pcs_gc_jacobian
+int pcs_abi_version(void) { return 102; }  // 102: pcs_gc_segment_gradient, pcs_*_derivatives_vjp
 
 const char* pcs_last_error(void) { return g_err; }
 
@@ -449,6 +477,21 @@ int pcs_pure_derivatives(const double* params, const double* temp, const double*
                        dp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_pure_derivatives launch", e);
+    return 0;
+}
+
+int pcs_pure_derivatives_vjp(const double* params, const double* temp, const double* rho, int64_t n, const double* g_a,
+                             const double* g_p, const double* g_dp, double* grad_params, double* grad_temp, double* grad_rho,
+                             void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !temp || !rho) return fail_msg("pcs_pure_derivatives_vjp: null required pointer");
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_pure_derivatives_vjp, dim3(grid), dim3(BLOCK), 0, as_stream(stream), params, temp, rho, n, g_a, g_p,
+                       g_dp, grad_params, grad_temp, grad_rho);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_derivatives_vjp launch", e);
     return 0;
 }
 

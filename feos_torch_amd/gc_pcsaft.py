@@ -96,6 +96,75 @@ def build_table(seg, kab):
     return torch.cat([seg.reshape(-1), (ee.sqrt() * s3).reshape(-1), (ee * s3).reshape(-1), (1.0 - kab).reshape(-1)]).contiguous()
 
 
+def _kab_gradient(table, S, rows, ph, T, dA01, dB01):
+    """[S,S] gradient w.r.t. k_ab from the per-row derivatives w.r.t. the mixed aggregates A01, B01 (upstream gradient
+    already folded in): d A01 / d K_ab = 2 sqrt(phi0 phi1)/T m0a m1b E1_ab, d B01 / d K_ab = 4 phi0 phi1/T^2 m0a m1b E2_ab K_ab
+    with K = 1 - k_ab (feos_torch/gc_pcsaft.py:177-194)."""
+    seg_m = table[: S * 8].view(S, 8)[:, 0]
+    E1 = table[S * 8: S * 8 + S * S].view(S, S)
+    E2 = table[S * 8 + S * S: S * 8 + 2 * S * S].view(S, S)
+    K = table[S * 8 + 2 * S * S:].view(S, S)
+    M = []
+    for c in range(2):  # m-weighted dense counts, built on the device from the row encoding
+        ids = rows[:, 8 * c:8 * c + 8].long()
+        cnt = rows[:, 16 + 8 * c:16 + 8 * c + 8].to(torch.float64)
+        Mc = torch.zeros((rows.shape[0], S), dtype=torch.float64, device=rows.device)
+        Mc.scatter_add_(1, ids, cnt * seg_m[ids])
+        M.append(Mc)
+    pp = ph[:, 0] * ph[:, 1]
+    w1 = dA01 * 2.0 * pp.sqrt() / T
+    w2 = dB01 * 4.0 * pp / (T * T)
+    G1 = M[0].t() @ (w1[:, None] * M[1])
+    G2 = M[0].t() @ (w2[:, None] * M[1])
+    return -(E1 * G1) - (E2 * K) * G2
+
+
+def _phi_gradient(dAB, agg, ph):
+    """[n,2] gradient w.r.t. phi from the per-row derivatives dAB [n,6] w.r.t. the aggregates (A ~ phi_i, sqrt(phi_0 phi_1),
+    B ~ phi_i^2, phi_0 phi_1)."""
+    A00, A01, A11, B00, B01, B11 = (agg[:, k] for k in range(6))
+    d0 = dAB[:, 0] * A00 + 0.5 * dAB[:, 1] * A01 + 2.0 * dAB[:, 3] * B00 + dAB[:, 4] * B01
+    d1 = dAB[:, 2] * A11 + 0.5 * dAB[:, 1] * A01 + 2.0 * dAB[:, 5] * B11 + dAB[:, 4] * B01
+    return torch.stack([d0 / ph[:, 0], d1 / ph[:, 1]], dim=1)
+
+
+class _GcDerivatives(torch.autograd.Function):
+    """(a, p, mu, v) = derivatives(...) with gradients to k_ab, phi, temperature, density and the eight segment parameter
+    vectors (feos_torch/gc_pcsaft.py:116-253, :443-468 are torch graphs in the reference)."""
+
+    @staticmethod
+    def forward(ctx, model, kab, phi, temperature, density, *segment_parameters):
+        dev = model.device
+        table = build_table(model.seg.to(dev), kab.detach().to(dev, torch.float64))
+        ph = native._prep(phi, dev, (2,))
+        T = native._prep(temperature, dev)
+        rho = native._prep(density, dev, (2,))
+        a, p, mu, v = native.gc_derivatives(table, model.S, model.rows, ph, T, rho)
+        ctx.save_for_backward(table, model.rows, ph, T, rho)
+        ctx.set_materialize_grads(False)
+        ctx.S = model.S
+        ctx.devs = (kab.device, phi.device, temperature.device, density.device)
+        ctx.seg_devs = [q.device for q in segment_parameters]
+        out = phi.device
+        return a.to(out), p.to(out), mu.to(out), v.to(out)
+
+    @staticmethod
+    def backward(ctx, g_a, g_p, g_mu, g_v):
+        table, rows, ph, T, rho = ctx.saved_tensors
+        nseg = len(ctx.seg_devs)
+        if g_a is None and g_p is None and g_mu is None and g_v is None:
+            return (None,) * (5 + nseg)
+        S = ctx.S
+        gseg, jac9, agg = native.gc_derivatives_vjp(table, S, rows, ph, T, rho, g_a, g_p, g_mu, g_v)
+        need = ctx.needs_input_grad
+        gk = _kab_gradient(table, S, rows, ph, T, jac9[:, 1], jac9[:, 4]).to(ctx.devs[0]) if need[1] else None
+        gphi = _phi_gradient(jac9, agg, ph).to(ctx.devs[1]) if need[2] else None
+        gT = jac9[:, 6].contiguous().to(ctx.devs[2]) if need[3] else None
+        grho = jac9[:, 7:9].contiguous().to(ctx.devs[3]) if need[4] else None
+        gs = [gseg[:, k].to(ctx.seg_devs[k]) if need[5 + k] else None for k in range(nseg)]
+        return (None, gk, gphi, gT, grho, *gs)
+
+
 class _GcBubbleDew(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dew, model, kab, phi, temperature, molefracs, pressure, *segment_parameters):
@@ -144,30 +213,10 @@ class _GcBubbleDew(torch.autograd.Function):
         g = g_value.to(jac.device)
         gk = gphi = gT = None
         if ctx.needs[0]:
-            # m-weighted dense counts of the converged rows, built on the device from the row encoding
-            seg_m = table[: S * 8].view(S, 8)[:, 0]
-            E1 = table[S * 8: S * 8 + S * S].view(S, S)
-            E2 = table[S * 8 + S * S: S * 8 + 2 * S * S].view(S, S)
-            K = table[S * 8 + 2 * S * S:].view(S, S)
-            M = []
-            for c in range(2):
-                ids = rows[:, 8 * c:8 * c + 8].long()
-                cnt = rows[:, 16 + 8 * c:16 + 8 * c + 8].to(torch.float64)
-                Mc = torch.zeros((rows.shape[0], S), dtype=torch.float64, device=rows.device)
-                Mc.scatter_add_(1, ids, cnt * seg_m[ids])
-                M.append(Mc)
-            pp = ph[:, 0] * ph[:, 1]
-            w1 = g * jac[:, 1] * 2.0 * pp.sqrt() / T          # d A01 / d K_ab = w-part * m0a m1b E1_ab
-            w2 = g * jac[:, 4] * 4.0 * pp / (T * T)            # d B01 / d K_ab = w-part * m0a m1b E2_ab K_ab
-            G1 = M[0].t() @ (w1[:, None] * M[1])
-            G2 = M[0].t() @ (w2[:, None] * M[1])
-            gk = (-(E1 * G1) - (E2 * K) * G2).to(ctx.devs[0])  # K = 1 - k_ab
+            gk = _kab_gradient(table, S, rows, ph, T, g * jac[:, 1], g * jac[:, 4]).to(ctx.devs[0])
         if ctx.needs[1]:
             gphi = torch.zeros((n, 2), dtype=torch.float64, device=jac.device)
-            A00, A01, A11, B00, B01, B11 = (agg[:, k] for k in range(6))
-            d0 = jac[:, 0] * A00 + 0.5 * jac[:, 1] * A01 + 2.0 * jac[:, 3] * B00 + jac[:, 4] * B01
-            d1 = jac[:, 2] * A11 + 0.5 * jac[:, 1] * A01 + 2.0 * jac[:, 5] * B11 + jac[:, 4] * B01
-            gphi[ok] = torch.stack([g * d0 / ph[:, 0], g * d1 / ph[:, 1]], dim=1)
+            gphi[ok] = g[:, None] * _phi_gradient(jac, agg, ph)
             gphi = gphi.to(ctx.devs[1])
         if ctx.needs[2]:
             gT = torch.zeros(n, dtype=torch.float64, device=jac.device)
@@ -226,13 +275,15 @@ class GcPcSaftMix:
         return build_table(self.seg.to(self.device), self.kab.detach().to(self.device))
 
     def helmholtz_energy_density(self, temperature, density, kab=None):
+        """a(T, rho_1, rho_2) [A^-3], shape [N, 1] (:116-253); differentiable."""
         return self.derivatives(temperature, density)[0][:, None]
 
     def derivatives(self, temperature, density):
-        """(a, p, mu [N,2], v [N,2]) (:443-468).  Forward only."""
-        a, p, mu, v = native.gc_derivatives(self._table(), self.S, self.rows, self.phi, temperature, density)
-        dev = self.phi.device
-        return a.to(dev), p.to(dev), mu.to(dev), v.to(dev)
+        """(a, p, mu [N,2], v [N,2]) (:443-468); differentiable w.r.t. the segment parameters, k_ab, phi, temperature and
+        density (pcs_gc_derivatives_vjp is the backward pass)."""
+        temperature = torch.as_tensor(temperature, dtype=torch.float64)
+        density = torch.as_tensor(density, dtype=torch.float64)
+        return _GcDerivatives.apply(self, self.kab, self.phi, temperature, density, *self._segment_parameters)
 
     def bubble_point(self, temperature, liquid_molefracs, pressure):
         """(p [Pa], nans) (:470-490)."""

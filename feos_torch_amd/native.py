@@ -435,3 +435,70 @@ def gc_segment_gradient(table, S, rows, phi, temperature, rho4, dew, gout=None, 
                                        _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_gc_segment_gradient")
     return grad
+
+
+def _opt(x, device, shape_tail=None):
+    return None if x is None else _prep(x, device, shape_tail)
+
+
+def pure_derivatives_vjp(params, temperature, density, g_a=None, g_p=None, g_dp=None):
+    """Backward of PcSaftPure.derivatives: -> (grad_params [n,8], grad_T [n], grad_rho [n])."""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    params = _prep(params, device, (8,))
+    temperature, density = _prep(temperature, device), _prep(density, device)
+    g_a, g_p, g_dp = _opt(g_a, device), _opt(g_p, device), _opt(g_dp, device)
+    n = temperature.shape[0]
+    _same_rows(n, parameters=params, density=density, g_a=g_a, g_p=g_p, g_dp=g_dp)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        gpar = torch.empty((n, 8), dtype=_F64, device=device)
+        gT = torch.empty(n, dtype=_F64, device=device)
+        grho = torch.empty(n, dtype=_F64, device=device)
+        rc = L.pcs_pure_derivatives_vjp(_lib.ptr(params), _lib.ptr(temperature), _lib.ptr(density), n, _lib.ptr(g_a),
+                                        _lib.ptr(g_p), _lib.ptr(g_dp), _lib.ptr(gpar), _lib.ptr(gT), _lib.ptr(grho),
+                                        _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_pure_derivatives_vjp")
+    return gpar, gT, grho
+
+
+def mix_derivatives_vjp(params, kij, temperature, density, g_a=None, g_p=None, g_mu=None, g_v=None):
+    """Backward of PcSaftMix.derivatives: -> grad [n,21] = dL/d(16 parameters, kij0, kij1, T, rho_0, rho_1)."""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    params = _prep(params, device, (2, 8))
+    kij = _prep(kij, device, (2,))
+    temperature, density = _prep(temperature, device), _prep(density, device, (2,))
+    g_a, g_p, g_mu, g_v = _opt(g_a, device), _opt(g_p, device), _opt(g_mu, device, (2,)), _opt(g_v, device, (2,))
+    n = temperature.shape[0]
+    _same_rows(n, parameters=params, kij=kij, density=density, g_a=g_a, g_p=g_p, g_mu=g_mu, g_v=g_v)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        grad = torch.empty((n, 21), dtype=_F64, device=device)
+        ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
+        rc = L.pcs_mix_derivatives_vjp(_lib.ptr(params), _lib.ptr(kij), _lib.ptr(temperature), _lib.ptr(density), n,
+                                       _lib.ptr(g_a), _lib.ptr(g_p), _lib.ptr(g_mu), _lib.ptr(g_v), _lib.ptr(grad),
+                                       _lib.ptr(ws), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_mix_derivatives_vjp")
+    return grad
+
+
+def gc_derivatives_vjp(table, S, rows, phi, temperature, density, g_a=None, g_p=None, g_mu=None, g_v=None, order=None):
+    """Backward of GcPcSaftMix.derivatives: -> (grad_seg [S,8], jac9 [n,9] = dL/d(6 aggregates, T, rho_0, rho_1), agg [n,6])."""
+    device = table.device
+    phi = _prep(phi, device, (2,))
+    temperature, density = _prep(temperature, device), _prep(density, device, (2,))
+    g_a, g_p, g_mu, g_v = _opt(g_a, device), _opt(g_p, device), _opt(g_mu, device, (2,)), _opt(g_v, device, (2,))
+    n = temperature.shape[0]
+    _check_gc(table, S, rows, n)
+    _same_rows(n, phi=phi, density=density, g_a=g_a, g_p=g_p, g_mu=g_mu, g_v=g_v)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        gseg = torch.zeros((int(S), 8), dtype=_F64, device=device)
+        jac9 = torch.empty((n, 9), dtype=_F64, device=device)
+        agg = torch.empty((n, 6), dtype=_F64, device=device)
+        rc = L.pcs_gc_derivatives_vjp(_lib.ptr(table), int(S), _lib.ptr(rows), _lib.ptr(phi), _lib.ptr(temperature),
+                                      _lib.ptr(density), n, _lib.ptr(g_a), _lib.ptr(g_p), _lib.ptr(g_mu), _lib.ptr(g_v),
+                                      _lib.ptr(gseg), _lib.ptr(jac9), _lib.ptr(agg),
+                                      _lib.ptr(order) if order is not None and order.shape[0] == n else None,
+                                      _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_gc_derivatives_vjp")
+    return gseg, jac9, agg

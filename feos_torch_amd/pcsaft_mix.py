@@ -72,6 +72,36 @@ class _BubbleDew(torch.autograd.Function):
         return None, gp, gk, gt, None, None
 
 
+class _MixDerivatives(torch.autograd.Function):
+    """(a, p, mu, v) = derivatives(parameters[n,2,8], kij[n,2], temperature[n], density[n,2]) with gradients to all four
+    inputs (feos_torch/pcsaft_mix.py:31-154, :395-420 are torch graphs in the reference)."""
+
+    @staticmethod
+    def forward(ctx, parameters, kij, temperature, density):
+        dev = native._dev() if not parameters.is_cuda else parameters.device
+        par = native._prep(parameters, dev, (2, 8))
+        k = native._prep(kij, dev, (2,))
+        T = native._prep(temperature, dev)
+        rho = native._prep(density, dev, (2,))
+        a, p, mu, v = native.mix_derivatives(par, k, T, rho)
+        ctx.save_for_backward(par, k, T, rho)
+        ctx.set_materialize_grads(False)
+        ctx.in_devices = (parameters.device, kij.device, temperature.device, density.device)
+        out = parameters.device
+        return a.to(out), p.to(out), mu.to(out), v.to(out)
+
+    @staticmethod
+    def backward(ctx, g_a, g_p, g_mu, g_v):
+        par, k, T, rho = ctx.saved_tensors
+        if g_a is None and g_p is None and g_mu is None and g_v is None:
+            return None, None, None, None
+        g = native.mix_derivatives_vjp(par, k, T, rho, g_a, g_p, g_mu, g_v)
+        need, d = ctx.needs_input_grad, ctx.in_devices
+        n = T.shape[0]
+        return (g[:, 0:16].reshape(n, 2, 8).to(d[0]) if need[0] else None, g[:, 16:18].contiguous().to(d[1]) if need[1] else None,
+                g[:, 18].contiguous().to(d[2]) if need[2] else None, g[:, 19:21].contiguous().to(d[3]) if need[3] else None)
+
+
 class PcSaftMix:
     def __init__(self, parameters, kij=None):
         """parameters: [N, 2, 8] float64 (component rows as for PcSaftPure); kij: [N, 2] with
@@ -104,14 +134,15 @@ class PcSaftMix:
         return self.kij.detach().cpu().numpy()
 
     def helmholtz_energy_density(self, temperature, density):
-        """a(T, rho_1, rho_2) [A^-3], shape [N, 1] like the reference (:31-154).  Forward only."""
+        """a(T, rho_1, rho_2) [A^-3], shape [N, 1] like the reference (:31-154); differentiable."""
         return self.derivatives(temperature, density)[0][:, None]
 
     def derivatives(self, temperature, density):
-        """(a [N], p [N], mu [N,2], v [N,2]) (:395-420).  Forward only."""
-        a, p, mu, v = native.mix_derivatives(self._par, self.kij, temperature, density)
-        dev = self._par.device
-        return a.to(dev), p.to(dev), mu.to(dev), v.to(dev)
+        """(a [N], p [N], mu [N,2], v [N,2]) (:395-420); differentiable w.r.t. parameters, kij, temperature and density
+        (pcs_mix_derivatives_vjp is the backward pass)."""
+        temperature = torch.as_tensor(temperature, dtype=torch.float64)
+        density = torch.as_tensor(density, dtype=torch.float64)
+        return _MixDerivatives.apply(self._par, self.kij, temperature, density)
 
     def bubble_point(self, temperature, liquid_molefracs, pressure):
         """(p [Pa], nans) at T [K], liquid mole fraction of component 1, initial pressure [Pa] (:422-444)."""

@@ -91,6 +91,34 @@ class _PureProperty(torch.autograd.Function):
         return None, gp, gt, gpr
 
 
+class _PureDerivatives(torch.autograd.Function):
+    """(a, p, dp) = derivatives(parameters[n,8], temperature[n], density[n]) with the reference's autograd behaviour
+    (feos_torch/pcsaft_pure.py:106-182 are torch graphs): gradients to parameters, temperature and density."""
+
+    @staticmethod
+    def forward(ctx, parameters, temperature, density):
+        dev = native._dev() if not parameters.is_cuda else parameters.device
+        par = native._prep(parameters, dev, (8,))
+        T = native._prep(temperature, dev)
+        rho = native._prep(density, dev)
+        a, p, dp = native.pure_derivatives(par, T, rho)
+        ctx.save_for_backward(par, T, rho)
+        ctx.set_materialize_grads(False)
+        ctx.in_devices = (parameters.device, temperature.device, density.device)
+        out = parameters.device
+        return a.to(out), p.to(out), dp.to(out)
+
+    @staticmethod
+    def backward(ctx, g_a, g_p, g_dp):
+        par, T, rho = ctx.saved_tensors
+        if g_a is None and g_p is None and g_dp is None:
+            return None, None, None
+        gpar, gT, grho = native.pure_derivatives_vjp(par, T, rho, g_a, g_p, g_dp)
+        need = ctx.needs_input_grad
+        return (gpar.to(ctx.in_devices[0]) if need[0] else None, gT.to(ctx.in_devices[1]) if need[1] else None,
+                grho.to(ctx.in_devices[2]) if need[2] else None)
+
+
 class PcSaftPure:
     def __init__(self, parameters):
         """parameters: [N, 8] float64 — m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb
@@ -118,14 +146,15 @@ class PcSaftPure:
 
     # -- state functions -------------------------------------------------------------------
     def helmholtz_energy(self, temperature, density):
-        """Reduced residual Helmholtz energy density a(T, rho) [A^-3] (:106-178).  Forward only."""
+        """Reduced residual Helmholtz energy density a(T, rho) [A^-3] (:106-178); differentiable w.r.t. parameters,
+        temperature and density like the reference's torch graph."""
         return self.derivatives(temperature, density)[0]
 
     def derivatives(self, temperature, density):
-        """(a, p, dp/drho), all reduced (:180-182).  Forward only (no autograd graph)."""
-        a, p, dp = native.pure_derivatives(self._par, temperature, density)
-        dev = self._par.device
-        return a.to(dev), p.to(dev), dp.to(dev)
+        """(a, p, dp/drho), all reduced (:180-182); differentiable (pcs_pure_derivatives_vjp is the backward pass)."""
+        temperature = torch.as_tensor(temperature, dtype=torch.float64)
+        density = torch.as_tensor(density, dtype=torch.float64)
+        return _PureDerivatives.apply(self._par, temperature, density)
 
     # -- properties ------------------------------------------------------------------------
     def liquid_density(self, temperature, pressure):

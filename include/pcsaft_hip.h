@@ -195,6 +195,37 @@ int pcs_gc_segment_gradient(int dew, const double* table, int S, const uint8_t* 
                             const double* rho4, int64_t n, const double* gout, double* grad_seg, const int32_t* order,
                             void* stream);
 
+/*
+ * ---- vector-Jacobian products of the state functions -------------------------------------------------------------
+ * In the reference helmholtz_energy(_density) and derivatives are ordinary torch graphs (feos_torch/pcsaft_pure.py:106-182,
+ * pcsaft_mix.py:31-154 / :395-420, gc_pcsaft.py:116-253 / :443-468): a loss built on their outputs back-propagates to the
+ * parameters, the temperature and the densities.  These entry points are that backward pass: upstream gradients of the
+ * outputs in (NULL = that output does not enter the loss), gradients of the loss w.r.t. the inputs out.  Forward mode
+ * inside (dual-number directions per pass), contracted with the upstream gradients in the kernel.
+ */
+
+/* PcSaftPure.derivatives -> (a, p, dp).  g_a, g_p, g_dp [n] in; grad_params [n,8], grad_temp [n], grad_rho [n] out
+ * (each optional). */
+int pcs_pure_derivatives_vjp(const double* params, const double* temp, const double* rho, int64_t n, const double* g_a,
+                             const double* g_p, const double* g_dp, double* grad_params, double* grad_temp, double* grad_rho,
+                             void* stream);
+
+/* PcSaftMix.derivatives -> (a, p, mu [n,2], v [n,2]).  g_a, g_p [n], g_mu, g_v [n,2] in;
+ * grad [n,21] = dL/d(params[0,0..7], params[1,0..7], kij[0], kij[1], T, rho_0, rho_1) out.
+ * workspace: optional device scratch of pcs_workspace_bytes(n) (batch-wide class order, as pcs_mix_jacobian). */
+int pcs_mix_derivatives_vjp(const double* params, const double* kij, const double* temp, const double* rho, int64_t n,
+                            const double* g_a, const double* g_p, const double* g_mu, const double* g_v, double* grad,
+                            void* workspace, void* stream);
+
+/* GcPcSaftMix.derivatives -> (a, p, mu, v).  Upstream gradients as for pcs_mix_derivatives_vjp;
+ *   grad_seg [S*8] inout  += sum_i dL_i / d seg[S,8]  (accumulated, caller zeroes; see pcs_gc_segment_gradient)
+ *   jac9     [n,9]  out   dL_i / d (A00, A01, A11, B00, B01, B11, T, rho_0, rho_1): k_ab and phi enter through the
+ *                         six dispersion aggregates (see pcs_gc_jacobian), the caller chains them
+ *   agg      [n,6]  out   the aggregate values (optional) */
+int pcs_gc_derivatives_vjp(const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
+                           const double* rho, int64_t n, const double* g_a, const double* g_p, const double* g_mu,
+                           const double* g_v, double* grad_seg, double* jac9, double* agg, const int32_t* order, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,3 +211,102 @@ def make_gc_seggrad(GcPcSaftMix, dump, tl):
         # full table incl. '>C<' (epsilon_k = 0): the reference's epsilon_k column is NaN, m / sigma / ... are finite
         g[name + "_full_table"] = _seggrad_case(GcPcSaftMix, tl, table, SEGGRAD_PAIRS + [("neopentane", "C5")], dew, w)
     dump("gc_seggrad.json", g)
+
+
+# ------------------------------------------------------------------------------------------
+# reference autograd THROUGH derivatives / helmholtz_energy(_density) (plain torch graphs in the reference:
+# feos_torch/pcsaft_pure.py:106-182, pcsaft_mix.py:31-154 / :395-420, gc_pcsaft.py:116-253 / :443-468) -> deriv_grad.json
+# loss = sum_i (w_a a + w_p p + ...)_i with seeded weights per row and output; rows are independent, so the input
+# gradients are per-row quantities
+# ------------------------------------------------------------------------------------------
+def _pure_deriv_grad(PcSaftPure, tl, params, T, rho, rng):
+    n = len(T)
+    x = torch.tensor(params, dtype=f64, requires_grad=True)
+    Tt = torch.tensor(T, dtype=f64, requires_grad=True)
+    rt = torch.tensor(rho, dtype=f64, requires_grad=True)
+    w = rng.uniform(-1.0, 1.0, size=(3, n))
+    a, p, dp = PcSaftPure(x).derivatives(Tt, rt)
+    (a * torch.tensor(w[0]) + p * torch.tensor(w[1]) + dp * torch.tensor(w[2])).sum().backward()
+    out = {"params": params, "T": T, "rho": rho, "w": w.tolist(), "grad_params": tl(x.grad), "grad_T": tl(Tt.grad), "grad_rho": tl(rt.grad)}
+    # helmholtz_energy alone
+    x2 = torch.tensor(params, dtype=f64, requires_grad=True)
+    T2 = torch.tensor(T, dtype=f64, requires_grad=True)
+    r2 = torch.tensor(rho, dtype=f64, requires_grad=True)
+    PcSaftPure(x2).helmholtz_energy(T2, r2).sum().backward()
+    out["a_only"] = {"grad_params": tl(x2.grad), "grad_T": tl(T2.grad), "grad_rho": tl(r2.grad)}
+    return out
+
+
+def _mix_deriv_grad(PcSaftMix, tl, params, kij, T, rho, rng):
+    n = len(T)
+    x = torch.tensor(params, dtype=f64, requires_grad=True)
+    k = torch.tensor(kij, dtype=f64, requires_grad=True)
+    Tt = torch.tensor(T, dtype=f64, requires_grad=True)
+    rt = torch.tensor(rho, dtype=f64, requires_grad=True)
+    w = rng.uniform(-1.0, 1.0, size=(6, n))
+    a, p, mu, v = PcSaftMix(x, k).derivatives(Tt, rt)
+    wt = torch.tensor(w)
+    (a * wt[0] + p * wt[1] + mu[:, 0] * wt[2] + mu[:, 1] * wt[3] + v[:, 0] * wt[4] + v[:, 1] * wt[5]).sum().backward()
+    return {"params": params, "kij": kij, "T": T, "rho": rho, "w": w.tolist(), "grad_params": tl(x.grad), "grad_kij": tl(k.grad),
+            "grad_T": tl(Tt.grad), "grad_rho": tl(rt.grad)}
+
+
+def _gc_deriv_grad(GcPcSaftMix, tl, table, seg_l, bon_l, kab_list, phi, T, rho, rng):
+    n = len(T)
+    ident = [s for s, _ in table]
+    cols = [torch.tensor([v[k] for _, v in table], dtype=f64, requires_grad=True) for k in range(8)]
+    kab = torch.tensor([k[2] for k in kab_list], dtype=f64, requires_grad=True)
+    kl = [(k[0], k[1], kv) for k, kv in zip(kab_list, kab)]
+    ph = torch.tensor(phi, dtype=f64, requires_grad=True)
+    Tt = torch.tensor(T, dtype=f64, requires_grad=True)
+    rt = torch.tensor(rho, dtype=f64, requires_grad=True)
+    w = rng.uniform(-1.0, 1.0, size=(6, n))
+    a, p, mu, v = GcPcSaftMix(ident, tuple(cols), seg_l, bon_l, kl, ph).derivatives(Tt, rt)
+    wt = torch.tensor(w)
+    (a * wt[0] + p * wt[1] + mu[:, 0] * wt[2] + mu[:, 1] * wt[3] + v[:, 0] * wt[4] + v[:, 1] * wt[5]).sum().backward()
+    return {"segment_lists": seg_l, "bond_lists": bon_l, "kab_list": [list(k) for k in kab_list], "phi": phi, "T": T, "rho": rho,
+            "w": w.tolist(), "grad_segments": [tl(c.grad) for c in cols], "grad_kab": tl(kab.grad), "grad_phi": tl(ph.grad),
+            "grad_T": tl(Tt.grad), "grad_rho": tl(rt.grad)}
+
+
+def make_deriv_grad(PcSaftPure, PcSaftMix, GcPcSaftMix, dump, tl, pure_test_params):
+    import json
+    import os
+    from feos_torch_amd.synthetic import GC_KAB, load_segment_table
+    here = os.path.dirname(os.path.abspath(__file__))
+    rng = np.random.default_rng(53)
+    g = {"pure": {}, "mix": {}, "gc": {}}
+    # pure: the reference's test rows (tests/test_pcsaft_pure.py:10-21) at a vapour-like and a liquid-like density + seeded random rows
+    with open(os.path.join(here, "pure.json")) as f:
+        gp = json.load(f)
+    g["pure"]["test_inputs"] = _pure_deriv_grad(PcSaftPure, tl, pure_test_params * 2, [300.0] * 12, [0.001] * 6 + [0.012] * 6, rng)
+    g["pure"]["random"] = _pure_deriv_grad(PcSaftPure, tl, gp["random"]["params"], gp["random"]["T"], gp["random"]["rho"], rng)
+    # mixtures: the 14 reference cases (tests/test_pcsaft_mix.py:17-39) + the seeded random rows of mix.json
+    with open(os.path.join(here, "mix.json")) as f:
+        gm = json.load(f)
+    ti = gm["test_inputs"]
+    g["mix"]["test_inputs"] = _mix_deriv_grad(PcSaftMix, tl, ti["params"], ti["kij"], ti["T"], ti["rho"], rng)
+    rr = gm["random"]
+    g["mix"]["random"] = _mix_deriv_grad(PcSaftMix, tl, rr["params"], rr["kij"], rr["T"], rr["rho"], rng)
+    # gc: one pair per model class on the table without '>C<' (all reference gradients finite) and the reference's 11 test
+    # pairs on the full table (its epsilon_k and phi gradients are NaN there: sqrt(0) under autograd)
+    table = load_segment_table(os.path.join(os.path.dirname(here), "data", "sauer2014_hetero.json"))
+    no_c = [(s, v) for s, v in table if s != ">C<"]
+    seg_l, bon_l = [], []
+    for a, b in SEGGRAD_PAIRS:
+        (sa, ba), (sb, bb) = _mol(a), _mol(b)
+        seg_l.append([sa, sb])
+        bon_l.append([ba, bb])
+    n = len(seg_l)
+    phi = rng.uniform(0.9, 1.1, size=(n, 2)).tolist()
+    T = rng.uniform(250.0, 400.0, n).tolist()
+    rho = (np.stack([rng.uniform(0.2, 0.8, n), rng.uniform(0.2, 0.8, n)], axis=1) * (10.0 ** rng.uniform(-5, -2.4, n))[:, None]).tolist()
+    ident = [s for s, _ in no_c]
+    kl = [k for k in GC_KAB if k[0] in ident and k[1] in ident]
+    g["gc"]["classes"] = _gc_deriv_grad(GcPcSaftMix, tl, no_c, seg_l, bon_l, kl, phi, T, rho, rng)
+    g["gc"]["classes"]["table"] = ident
+    n = len(GC_TEST_SEGMENTS)
+    g["gc"]["test_inputs"] = _gc_deriv_grad(GcPcSaftMix, tl, table, GC_TEST_SEGMENTS, GC_TEST_BONDS, GC_TEST_KAB, [[1.1, 0.98]] * n,
+                                            [300.0] * n, [[0.001, 0.002]] * n, rng)
+    g["gc"]["test_inputs"]["table"] = [s for s, _ in table]
+    dump("deriv_grad.json", g)
