@@ -24,18 +24,16 @@ inline int check_n(int64_t n) {
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Device-side counters (retry-list count, work-queue control block) are zeroed by a KERNEL on the call's stream, not by
-// hipMemsetAsync: every operation of a call is then a kernel node, so a hipGraph capture of the call replays them in
-// the captured order (a memset node is executed by the runtime's blit path, which round 1 saw reordered against the
-// kernels of a replay issued behind pending work).
+// hipMemsetAsync: every operation of a call is then a kernel node of a hipGraph capture.  Established in round 2 with one
+// A/B run (profiles/r02_capture_ab.log): a capture of pcs_pure_vle replayed behind pending launches is bit-identical to the
+// eager call 3/3 times with this reset, while the same library with the hipMemsetAsync reset of round 1 ended its second
+// replay in a GPU memory access fault -- although every list consumer bounds count and entries by n, i.e. the fault is in
+// the replayed memset node itself, not in a kernel reading a stale list.
 template <int DUMMY = 0>
 __global__ void k_zero_ints(int32_t* __restrict__ p, int count) {
     for (int k = threadIdx.x; k < count; k += blockDim.x) p[k] = 0;
 }
 inline int zero_ints(int32_t* p, int count, hipStream_t s) {
-#ifdef PCS_ZERO_WITH_MEMSET  // A/B builds only (scripts/dev/capture_ab.py): round 1's hipMemsetAsync reset
-    hipError_t em = hipMemsetAsync(p, 0, sizeof(int32_t) * count, s);
-    return em == hipSuccess ? 0 : fail("hipMemsetAsync", em);
-#endif
     hipLaunchKernelGGL(k_zero_ints<0>, dim3(1), dim3(64), 0, s, p, count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_zero_ints launch", e);
