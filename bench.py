@@ -5,23 +5,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path (pcs_pure_vle: fused Helmholtz + Newton/VLE kernel and the
-robust pass for rare rows) over one batch of `--rows` synthetic state points per GPU
-(SURVEY.md §8d distribution, seed 2026 + rank), inputs resident in HBM.  Weak scaling: every
-rank solves its own `--rows` rows and keeps its results (rows are independent: the path has no
-exchange step, so there is no data-path collective; the step time is the MAX over ranks between
-two barriers).  `--gather` additionally re-assembles the (p_sat fp64, status u8) shards on every
-rank with an RCCL all-gather, chunk-overlapped with the solve, for callers that need the whole
-result everywhere (90 MB per rank and step: over xGMI that costs more than the 1.7 ms solve).
-Rank 0 prints ONE JSON line.
+One step = one pass of the hot path at the KERNEL level (the C ABI `pcs_pure_vle_fast` + `pcs_pure_vle_retry` on
+pre-allocated outputs: fused Helmholtz + Newton/VLE kernel, all-fp64 fallback kernel and the robust pass for rare rows)
+over one batch of `--rows` synthetic state points per GPU (SURVEY.md §8d distribution, seed 2026 + rank), inputs resident
+in HBM.  Rank 0 prints ONE JSON line:
 
-The line also carries
-  roofline      for the dominant kernel k_pure_vle: algorithmic bytes (81 B/solve) / its launch
-                duration measured with HIP events on the launch stream — reported against the
-                HBM roof as the metric demands, next to the fp64-VALU view that actually bounds
-                this path (the kernel is compute bound by ~2 orders of magnitude);
-  cpu_baseline  the CPU oracle (own port of the same algorithm; the reference's Rust/feos path
-                cannot be built here) timed on the host cores on a bounded sample.
+  value / ms_per_step   weak scaling, every rank solves its own `--rows` rows and keeps its results: rows are independent,
+                        the path has no exchange step (barrier + synchronize on both sides, MAX over ranks);
+  allgather             N > 1: the same step with the RCCL all-gather that re-assembles (p_sat fp64, status u8) on every
+                        rank (north_star), in `--chunks` sub-batches so that the collective of chunk k overlaps the
+                        solve of chunk k+1;
+  strong                N > 1: global batch fixed at `--rows` (1e7, the batch the metric is quoted on), rank r solves
+                        rows [r n/N, (r+1) n/N), without and with the all-gather;
+  variants              N = 1: the same batch through the all-fp64 kernel (densities returned), forward + Jacobian
+                        (what a parameter fit runs) and the Python API (PcSaftPure.vapor_pressure, forward and
+                        forward + backward, including its allocations and host synchronisation);
+  roofline              for the dominant kernel k_pure_vle: algorithmic bytes (81 B/solve) / its launch duration measured
+                        with HIP events on the launch stream, against the HBM roof as the metric demands, next to the
+                        VALU-issue view that actually bounds this path (profiles/pmc_traffic.json);
+  cpu_baseline          N = 1: the CPU oracle (own port; the reference's Rust/feos path cannot be built here) on the host
+                        cores, bounded sample.
 """
 import argparse
 import json
@@ -36,7 +39,6 @@ if ROOT not in sys.path:
 
 BYTES_PER_SOLVE = 81  # 64 B parameters + 8 B T read, 8 B p_sat + 1 B status written
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_FMA_PEAK_GWAVEINSTR = 457.0  # measured on MI355X: independent v_fma_f64 chains, G wave-instructions/s (scratch/valu_peak.hip)
 
 
 def parse():
@@ -44,10 +46,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="state points per GPU per step")
-    ap.add_argument("--chunks", type=int, default=4, help="sub-batches per step (gather/solve overlap, N>1)")
-    ap.add_argument("--gather", action="store_true",
-                    help="N>1: also re-assemble (p_sat, status) on every rank with an RCCL all-gather, chunk-overlapped with the solve")
+    ap.add_argument("--rows", type=int, default=10_000_000, help="state points per GPU per step (weak) / global batch (strong)")
+    ap.add_argument("--chunks", type=int, default=4, help="sub-batches per step of the all-gather legs (gather/solve overlap)")
+    ap.add_argument("--no-extra", action="store_true", help="headline leg only (no all-gather / strong / variants legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40_000_000, help="upper bound on the rows of the CPU baseline sample")
     return ap.parse_args()
@@ -62,7 +63,8 @@ def relaunch_under_torchrun(args):
 
 def load_pmc(rows):
     """Counter-derived figures of k_pure_vle from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json):
-    HBM bytes per launch and VALU wave-instructions per launch.  {} if absent or for another launch size."""
+    HBM bytes per launch, VALU wave-instructions per launch and their issue-cycle weighting.  {} if absent or for another
+    launch size."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -90,70 +92,147 @@ def main():
     rank, world, device = pdist.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback in the product path)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    rows = args.rows
-    nchunk = args.chunks if (world > 1 and args.gather) else 1
-    assert rows % nchunk == 0
+    rows, steps, warmup = args.rows, args.steps, args.warmup
 
     # ---- inputs resident in HBM --------------------------------------------------------------
     P, T = pure_batch(rows, seed=2026 + rank)
     Pd = torch.from_numpy(P).to(device)
     Td = torch.from_numpy(T).to(device)
-    crow = rows // nchunk
-    plans = [native.PureVlePlan(crow, device) for _ in range(nchunk)]
-    Pc = [Pd[k * crow:(k + 1) * crow] for k in range(nchunk)]
-    Tc = [Td[k * crow:(k + 1) * crow] for k in range(nchunk)]
-    gather = world > 1 and args.gather
-    if gather:
-        g_p = [torch.empty(world * crow, dtype=torch.float64, device=device) for _ in range(nchunk)]
-        g_s = [torch.empty(world * crow, dtype=torch.uint8, device=device) for _ in range(nchunk)]
-
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps * nchunk)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps * nchunk)]
-
-    def step(i=None):
-        works = []
-        for k in range(nchunk):
-            if i is not None:
-                ev0[i * nchunk + k].record()
-            plans[k].run_fast(Pc[k], Tc[k])
-            if i is not None:
-                ev1[i * nchunk + k].record()
-            plans[k].run_retry(Pc[k], Tc[k])
-            if gather:  # NCCL stream waits for the kernels above, the next chunk's solve overlaps it
-                works.append(pdist.all_gather_flat(g_p[k], plans[k].p_sat, async_op=True))
-                works.append(pdist.all_gather_flat(g_s[k], plans[k].status, async_op=True))
-        for w in works:
-            w.wait()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(step):
+        """W untimed + exactly K timed calls of step(i) between barriers; seconds, MAX over ranks."""
+        for _ in range(warmup):
+            step(None)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
-    # ---- per-kernel duration of k_pure_vle from the HIP events (this rank) --------------------
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))  # per chunk launch
-    fails = sum(int(p.status.sum().item()) for p in plans)
-    counts = [p.retry_count() for p in plans]
-    fallback_rows, retry_rows = sum(c[0] for c in counts), sum(c[1] for c in counts)
+    # ---- headline leg: weak scaling, no data-path collective -----------------------------------
+    plan = native.PureVlePlan(rows, device)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+
+    def step_headline(i):
+        if i is not None:
+            ev0[i].record()
+        plan.run_fast(Pd, Td)  # k_pure_vle<pressure-only> + k_pure_vle_fallback
+        if i is not None:
+            ev1[i].record()
+        plan.run_retry(Pd, Td)  # robust pass over the (usually empty) list
+
+    dt = timed(step_headline)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    fails = int(plan.status.sum().item())
+    fallback_rows, retry_rows = plan.retry_count()
+
+    # ---- sharded legs with the all-gather (N > 1) ---------------------------------------------
+    def sharded_leg(Ps, Ts, gather):
+        """one step = solve of this rank's rows in chunks (+ all-gather of chunk k overlapped with the solve of k+1)"""
+        n_loc = Ts.shape[0]
+        nchunk = args.chunks if gather else 1
+        bounds = [(n_loc * k) // nchunk for k in range(nchunk + 1)]
+        plans = [native.PureVlePlan(bounds[k + 1] - bounds[k], device) for k in range(nchunk)]
+        if gather:
+            mx = max(p.n for p in plans)  # equal message sizes across ranks: shards differ by at most one row
+            mx_t = torch.tensor([mx], dtype=torch.int64, device=device)
+            dist.all_reduce(mx_t, op=dist.ReduceOp.MAX)
+            mx = int(mx_t.item())
+            send_p = [torch.zeros(mx, dtype=torch.float64, device=device) for _ in range(nchunk)]
+            send_s = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(nchunk)]
+            g_p = [torch.empty(world * mx, dtype=torch.float64, device=device) for _ in range(nchunk)]
+            g_s = [torch.empty(world * mx, dtype=torch.uint8, device=device) for _ in range(nchunk)]
+            for k, p in enumerate(plans):  # the kernels write straight into the send buffers
+                p.p_sat, p.status = send_p[k][: p.n], send_s[k][: p.n]
+
+        def step(_i):
+            works = []
+            for k, p in enumerate(plans):
+                lo, hi = bounds[k], bounds[k + 1]
+                p.run(Ps[lo:hi], Ts[lo:hi])
+                if gather:  # the RCCL stream waits for the kernels above only; the next chunk's solve overlaps it
+                    works.append(pdist.all_gather_flat(g_p[k], send_p[k], async_op=True))
+                    works.append(pdist.all_gather_flat(g_s[k], send_s[k], async_op=True))
+            for w in works:
+                w.wait()
+
+        return timed(step)
+
+    extra = {}
+    if world > 1 and not args.no_extra:
+        t_g = sharded_leg(Pd, Td, True)
+        extra["allgather"] = {
+            "value": world * rows * steps / t_g, "unit": "solves/s", "ms_per_step": t_g / steps * 1e3, "scaling": "weak",
+            "chunks": args.chunks, "bytes_gathered_per_rank_per_step": 9 * rows * (world - 1),
+            "note": "the headline step + RCCL all-gather of (p_sat fp64, status u8) onto every rank, chunk-overlapped",
+        }
+        # strong scaling: the global batch of the metric (rank 0's synthetic batch, the same on every rank) cut into
+        # contiguous shards
+        Pg, Tg = pure_batch(rows, seed=2026)
+        lo, hi = pdist.shard_bounds(rows, rank, world)
+        Ps, Ts = torch.from_numpy(Pg[lo:hi]).to(device), torch.from_numpy(Tg[lo:hi]).to(device)
+        t_s = sharded_leg(Ps, Ts, False)
+        t_sg = sharded_leg(Ps, Ts, True)
+        extra["strong"] = {
+            "global_rows": rows, "rows_per_gpu": hi - lo, "scaling": "strong", "unit": "solves/s",
+            "value": rows * steps / t_s, "ms_per_step": t_s / steps * 1e3,
+            "value_with_allgather": rows * steps / t_sg, "ms_per_step_with_allgather": t_sg / steps * 1e3,
+        }
+        del Ps, Ts
+
+    # ---- variants of the same batch on one GPU ---------------------------------------------------
+    if world == 1 and not args.no_extra:
+        variants = {}
+        full = native.PureVlePlan(rows, device, want_rho_vl=True)  # all-fp64 kernel k_pure_vle<false>, returns the densities
+        t_f = timed(lambda _i: full.run(Pd, Td))
+        variants["all_fp64_kernel"] = {"value": rows * steps / t_f, "ms_per_step": t_f / steps * 1e3,
+                                       "what": "k_pure_vle<false>: fp64 D2 finish, p_sat + (rho_V, rho_L) returned"}
+
+        def fwd_jac(_i):
+            full.run(Pd, Td)
+            native.pure_jacobian("vapor_pressure", Pd, Td, None, full.rho_vl)
+
+        t_j = timed(fwd_jac)
+        variants["forward_plus_jacobian"] = {"value": rows * steps / t_j, "ms_per_step": t_j / steps * 1e3,
+                                             "what": "all-fp64 solve + k_pure_jacobian<0>: d p_sat / d(8 parameters, T) per row"}
+        del full
+        from feos_torch_amd import PcSaftPure
+
+        def api_fwd(_i):
+            PcSaftPure(Pd).vapor_pressure(Td)
+
+        t_a = timed(api_fwd)
+        Pg = Pd.clone().requires_grad_(True)
+
+        def api_fwd_bwd(_i):
+            Pg.grad = None
+            _, p = PcSaftPure(Pg).vapor_pressure(Td)
+            p.sum().backward()
+
+        t_ab = timed(api_fwd_bwd)
+        variants["python_api"] = {"forward_value": rows * steps / t_a, "forward_ms": t_a / steps * 1e3,
+                                  "forward_backward_value": rows * steps / t_ab, "forward_backward_ms": t_ab / steps * 1e3,
+                                  "what": "PcSaftPure(params).vapor_pressure(T) incl. output allocation, status host sync and row filtering"}
+        del Pg
+        extra["variants"] = variants
 
     if rank == 0:
-        total = world * rows * args.steps
+        total = world * rows * steps
         value = total / dt
-        achieved = BYTES_PER_SOLVE * crow / (kern_ms * 1e-3) / 1e9
-        pmc = load_pmc(crow)
+        achieved = BYTES_PER_SOLVE * rows / (kern_ms * 1e-3) / 1e9
+        pmc = load_pmc(rows)
         traffic = pmc.get("hbm_bytes_per_launch")
         valu = pmc.get("valu_wave_instr_per_launch")
         line = {
@@ -161,19 +240,20 @@ def main():
             "value": value,
             "unit": "solves/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64 (fp32 pre-solve, fp64 finish)",
             "data": "synthetic",
             "config": {
-                "workload": f"PcSaftPure.vapor_pressure batch={rows:.0e} fp64 per GPU (fused Helmholtz+Newton kernel)",
+                "workload": f"pcs_pure_vle (C ABI behind PcSaftPure.vapor_pressure), batch={rows:.0e} fp64 rows per GPU, "
+                            "pre-allocated outputs, pressure-only kernel",
                 "rows_per_gpu": rows,
                 "global_rows": world * rows,
-                "parallelism": f"row-sharded x{world}" + (", all-gather(p_sat,status) overlapped" if gather else ", no data-path collective"),
+                "parallelism": f"row-sharded x{world}, no data-path collective in `value` (see `allgather` / `strong`)",
                 "seed": 2026,
                 "failed_rows_rank0": fails,
                 "fp64_fallback_rows_rank0": fallback_rows,
@@ -188,21 +268,25 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "bytes_per_solve": BYTES_PER_SOLVE,
-                "rows_per_launch": crow,
+                "rows_per_launch": rows,
                 "kernel_ms": kern_ms,
                 "note": "path is VALU-issue bound (arithmetic intensity >> machine balance); see DESIGN.md",
-                # the roofline that actually bounds the kernel: VALU issue.  Counted wave-instructions (PMC
-                # SQ_INSTS_VALU, profiles/) / measured kernel time vs the measured v_fma_f64 issue peak
-                # (the kernel mixes fp32 and fp64 VALU, so the fraction can exceed what fp64 alone allows)
+                # the roofline that actually bounds the kernel: VALU issue.  frac = sum over instruction classes of
+                # (counted wave-instructions x issue cycles of the class) / (SIMD-cycles of the launch), a number <= 1
+                # (scripts/summarise_profile.py: PMC instruction count split by the static fp32 / fp64 / transcendental mix)
                 "valu": None if not valu else {
                     "wave_instr_per_launch": valu,
-                    "instr_per_solve": valu * 64.0 / crow,
+                    "instr_per_solve": valu * 64.0 / rows,
                     "achieved_gwaveinstr_s": valu / (kern_ms * 1e-3) / 1e9,
-                    "fp64_fma_peak_gwaveinstr_s": FP64_FMA_PEAK_GWAVEINSTR,
+                    "frac": pmc.get("valu_issue_frac"),
+                    "issue_cycles_per_launch": pmc.get("valu_issue_cycles_per_launch"),
+                    "simd_cycles_per_launch": pmc.get("simd_cycles_per_launch"),
+                    "mix": pmc.get("valu_mix"),
                     "valu_busy_pmc": pmc.get("valu_busy"),
                 },
             },
         }
+        line.update(extra)
         if not args.no_cpu_baseline and world == 1:
             # OpenMP threads = CPUs this process may use (affinity mask capped by the cgroup quota)
             from oracle import pyoracle as _o

@@ -48,6 +48,39 @@ def test_pure_vapor_pressure_1e6(amd, oracle):
     assert int(r["status"].sum()) <= int(st.sum())  # the GPU path solves every row the oracle solves here
 
 
+def test_headline_batch_pressure_only_kernel(amd, oracle):
+    """The path bench.py times, on the batch bench.py times: the first 1e6 rows of pure_batch(1e7, seed=2026) through the
+    pressure-only kernel (k_pure_vle<true> + fallback + robust pass) vs the long-double oracle.
+      * every row: rtol 1e-9 (north_star);
+      * every row on which the reference's OWN fp64 formulas are well conditioned -- the literal double-precision
+        evaluation (oracle prec=0, feos_torch/pcsaft_pure.py:172-175 as written) agrees with the long-double one to
+        1e-11 -- : rtol 1e-10, the reference's tolerance for vapor_pressure (tests/test_pcsaft_pure.py:69);
+      * the remaining rows (strongly associating fluids far below the triple point, where the literal X_B cancels and
+        the reference itself is off by up to 1e-7): no worse than the reference's own fp64 error on that row."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch
+
+    P, T = pure_batch(10_000_000, seed=2026)
+    m = 1_000_000
+    P, T = np.ascontiguousarray(P[:m]), np.ascontiguousarray(T[:m])
+    r = native.pure_vle(_d(P), _d(T), want_rho_vl=False)
+    got, st_g = r["p_sat"].cpu().numpy(), r["status"].cpu().numpy().astype(bool)
+    want, st_o = oracle.pure_vapor_pressure(P, T, prec=1)
+    lit, st_l = oracle.pure_vapor_pressure(P, T, prec=0)
+    assert st_g.sum() <= st_o.sum()
+    both = ~st_g & ~st_o
+    rel = np.abs(got[both] - want[both]) / np.abs(want[both])
+    cond = np.where(st_l[both], np.inf, np.abs(lit[both] - want[both]) / np.abs(want[both]))  # the reference formula's fp64 error
+    well = cond <= 1e-11
+    print(f"rows {m}: both converged {both.sum()}, max rel {rel.max():.3e}; well-conditioned rows {well.sum()} max rel {rel[well].max():.3e}; "
+          f"ill-conditioned rows {(~well).sum()} max rel {rel[~well].max() if (~well).any() else 0:.3e} (reference fp64 error there up to "
+          f"{np.max(cond[np.isfinite(cond) & ~well]) if (~well).any() else 0:.3e}); rows > 1e-10: {(rel > 1e-10).sum()}")
+    assert both.mean() > 0.999
+    assert rel.max() < 1e-9
+    assert rel[well].max() <= 1e-10
+    assert np.all(rel[~well] <= np.maximum(1e-10, cond[~well]))
+
+
 def test_pure_liquid_densities_1e6(amd, oracle):
     from feos_torch_amd import native
     from feos_torch_amd.synthetic import pure_batch, pure_pressures
