@@ -75,6 +75,9 @@ def test_headline_batch_pressure_only_kernel(amd, oracle):
     print(f"rows {m}: both converged {both.sum()}, max rel {rel.max():.3e}; well-conditioned rows {well.sum()} max rel {rel[well].max():.3e}; "
           f"ill-conditioned rows {(~well).sum()} max rel {rel[~well].max() if (~well).any() else 0:.3e} (reference fp64 error there up to "
           f"{np.max(cond[np.isfinite(cond) & ~well]) if (~well).any() else 0:.3e}); rows > 1e-10: {(rel > 1e-10).sum()}")
+    idx = np.nonzero(both)[0]
+    for j in np.argsort(np.where(well, rel, 0.0))[::-1][:6]:
+        print(f"  worst well-conditioned: row {idx[j]} rel {rel[j]:.3e} cond {cond[j]:.1e} T {T[idx[j]]:.6f} p {want[idx[j]]:.6e} params {P[idx[j]].tolist()}")
     assert both.mean() > 0.999
     assert rel.max() < 1e-9
     assert rel[well].max() <= 1e-10
