@@ -140,10 +140,8 @@ S phi_self_assoc(const MixParams<S>& q, const S& T, const S* rho, const S* d, co
     S delta = association_strength(0, 0, T, s1, k1, e1, false, S(0.0), d1, zeta2, zeta3_m1);
     S rhoa = q.na[0] * rho[0] + q.na[1] * rho[1];
     S rhob = q.nb[0] * rho[0] + q.nb[1] * rho[1];
-    S aux = 1.0 + (rhoa - rhob) * delta;
-    S sq = sqrt(aux * aux + 4.0 * rhob * delta);
-    S xa = 2.0 / (sq + 1.0 + (rhob - rhoa) * delta);
-    S xb = 2.0 / (sq + 1.0 + (rhoa - rhob) * delta);
+    S xa, xb;
+    site_fractions_two_types(rhoa, rhob, delta, xa, xb);  // :235-238 (literal in double, conjugate forms in long double)
     return rhoa * site_f(xa) + rhob * site_f(xb);
 }
 

@@ -103,10 +103,8 @@ S helmholtz_energy(const PureParams<S>& q, const S& temperature, const S& densit
     S delta = (1.0 + k * (1.5 + 0.5 * k)) * eta_m1 * delta_assoc;
     S rhoa = q.na * density;
     S rhob = q.nb * density;
-    S aux = 1.0 + (rhoa - rhob) * delta;
-    S sq = sqrt(aux * aux + 4.0 * rhob * delta);
-    S xa = 2.0 / (sq + 1.0 + (rhob - rhoa) * delta);
-    S xb = 2.0 / (sq + 1.0 - (rhob - rhoa) * delta);
+    S xa, xb;
+    site_fractions_two_types(rhoa, rhob, delta, xa, xb);  // :172-175 (literal in double, conjugate forms in long double)
     S assoc = rhoa * (log(xa) - 0.5 * xa + 0.5) + rhob * (log(xb) - 0.5 * xb + 0.5);
 
     return hs + hc + disp + dipole + assoc;

@@ -50,13 +50,14 @@ def test_pure_vapor_pressure_1e6(amd, oracle):
 
 def test_headline_batch_pressure_only_kernel(amd, oracle):
     """The path bench.py times, on the batch bench.py times: the first 1e6 rows of pure_batch(1e7, seed=2026) through the
-    pressure-only kernel (k_pure_vle<true> + fallback + robust pass) vs the long-double oracle.
-      * every row: rtol 1e-9 (north_star);
-      * every row on which the reference's OWN fp64 formulas are well conditioned -- the literal double-precision
-        evaluation (oracle prec=0, feos_torch/pcsaft_pure.py:172-175 as written) agrees with the long-double one to
-        1e-11 -- : rtol 1e-10, the reference's tolerance for vapor_pressure (tests/test_pcsaft_pure.py:69);
-      * the remaining rows (strongly associating fluids far below the triple point, where the literal X_B cancels and
-        the reference itself is off by up to 1e-7): no worse than the reference's own fp64 error on that row."""
+    pressure-only kernel (k_pure_vle<true> + fallback + robust pass) vs the long-double oracle: rtol 1e-10 on EVERY row
+    both sides converge on -- the reference's own tolerance for vapor_pressure (tests/test_pcsaft_pure.py:69), ten times
+    tighter than north_star's 1e-9.
+    (Round 2: the first version of this test found three rows 1.1e-10 off.  A 50-digit mpmath referee
+    (tests/tools/mp_pure_check.py) showed the KERNEL right to 2e-13 and the long-double oracle wrong: the site-fraction
+    formula as written, feos_torch/pcsaft_pure.py:172-175, loses 10 digits at t ~ 1e10 even in 80-bit arithmetic.  The
+    oracle's long-double instantiation now uses the conjugate forms (oracle/dual.hpp); its plain-double one keeps the formula
+    as written and is printed below as the error the reference's own fp64 evaluation makes on this batch.)"""
     from feos_torch_amd import native
     from feos_torch_amd.synthetic import pure_batch
 
@@ -70,18 +71,14 @@ def test_headline_batch_pressure_only_kernel(amd, oracle):
     assert st_g.sum() <= st_o.sum()
     both = ~st_g & ~st_o
     rel = np.abs(got[both] - want[both]) / np.abs(want[both])
-    cond = np.where(st_l[both], np.inf, np.abs(lit[both] - want[both]) / np.abs(want[both]))  # the reference formula's fp64 error
-    well = cond <= 1e-11
-    print(f"rows {m}: both converged {both.sum()}, max rel {rel.max():.3e}; well-conditioned rows {well.sum()} max rel {rel[well].max():.3e}; "
-          f"ill-conditioned rows {(~well).sum()} max rel {rel[~well].max() if (~well).any() else 0:.3e} (reference fp64 error there up to "
-          f"{np.max(cond[np.isfinite(cond) & ~well]) if (~well).any() else 0:.3e}); rows > 1e-10: {(rel > 1e-10).sum()}")
+    ref_err = np.abs(lit[both & ~st_l] - want[both & ~st_l]) / np.abs(want[both & ~st_l])
     idx = np.nonzero(both)[0]
-    for j in np.argsort(np.where(well, rel, 0.0))[::-1][:6]:
-        print(f"  worst well-conditioned: row {idx[j]} rel {rel[j]:.3e} cond {cond[j]:.1e} T {T[idx[j]]:.6f} p {want[idx[j]]:.6e} params {P[idx[j]].tolist()}")
+    print(f"rows {m}: both converged {both.sum()}, max rel {rel.max():.3e}, q99.99 {np.quantile(rel, 0.9999):.3e}, rows > 1e-11: {(rel > 1e-11).sum()}; "
+          f"formulas as written in fp64 (reference Python): max rel {ref_err.max():.3e}, rows > 1e-10: {(ref_err > 1e-10).sum()}")
+    for j in np.argsort(rel)[::-1][:3]:
+        print(f"  worst: row {idx[j]} rel {rel[j]:.3e} T {T[idx[j]]:.6f} p {want[idx[j]]:.6e} params {P[idx[j]].tolist()}")
     assert both.mean() > 0.999
-    assert rel.max() < 1e-9
-    assert rel[well].max() <= 1e-10
-    assert np.all(rel[~well] <= np.maximum(1e-10, cond[~well]))
+    assert rel.max() <= 1e-10
 
 
 def test_pure_liquid_densities_1e6(amd, oracle):
