@@ -1,7 +1,9 @@
 """Large-batch parity of the GPU path (through the C ABI) against the CPU oracle at extended precision: 1e6 pure
 vapour pressures, 1e5 mixture bubble / dew points, 2.5e4 gc bubble / dew points on the seeded synthetic distributions
-(SURVEY.md section 8d).  north_star tolerance rtol 1e-9 on every row both sides converge on; the failure masks
-(which are the solver's, not pinned by any reference fixture) may differ on a few rows per 1e5."""
+(SURVEY.md section 8d).  Tolerance: rtol 1e-10 on every row both sides converge on -- the reference's own tolerance for
+its properties (tests/test_pcsaft_pure.py:69), ten times tighter than north_star's 1e-9 (measured in round 2, after the
+long-double oracle's site-fraction formula was made cancellation-free: 6e-12 pure, 4e-13 mixtures, 4e-14 gc); the failure
+masks (which are the solver's, not pinned by any reference fixture) may differ on a few rows per 1e5."""
 import os
 
 import numpy as np
@@ -26,6 +28,9 @@ def _d(x):
     return torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
 
+TOL = 1e-10
+
+
 def _check(got, st_g, want, st_o, max_mismatch):
     both = ~st_g & ~st_o
     rel = np.abs(got[both] - want[both]) / np.abs(want[both])
@@ -33,7 +38,7 @@ def _check(got, st_g, want, st_o, max_mismatch):
           f"gpu failed {st_g.sum()} oracle failed {st_o.sum()} mask mismatch {(st_g != st_o).sum()} "
           f"rows > 1e-9: {(rel > 1e-9).sum()} at {np.where(both)[0][rel > 1e-9][:8].tolist()}")
     assert both.mean() > 0.98
-    assert rel.max() < 1e-9, f"max rel {rel.max():.3e}, rows > 1e-9: {(rel > 1e-9).sum()}"
+    assert rel.max() < TOL, f"max rel {rel.max():.3e}, rows > {TOL}: {(rel > TOL).sum()}"
     assert (st_g != st_o).sum() <= max_mismatch, f"failure masks differ on {(st_g != st_o).sum()} rows"
 
 
