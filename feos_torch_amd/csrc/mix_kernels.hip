@@ -162,6 +162,10 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
     long long t0 = clock64();
 #endif
     int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, retry ? FAST_SS : SS_MAX_IT, retry ? FAST_NEWTON : NEWTON_MAX_IT);
+#if PCS_MIX_SM
+    // single pass without a work list (workspace == NULL): the robust second attempt runs in place
+    if (!retry && rc != BD_OK) rc = bubble_dew_solve_sm<DEW, MixModel, true>(m, z[i], p_red, r);
+#endif
 #ifdef PCS_MIX_DIAG
 #if PCS_MIX_DIAG == 3
     // r.iters already holds the evaluation count
@@ -180,8 +184,10 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
     mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
 }
 
-// K5 robust pass over the compacted list: same arithmetic, full caps (count read on the device)
-template <bool DEW>
+// K5 second pass over a compacted list (count read on the device).  ROBUST = false: the rows that hit a cap of the fast
+// pass, same arithmetic with the full caps (PCS_MIX_QUEUE = 0 builds).  ROBUST = true: the rows the work-queue kernel gave
+// up on, solved again with bracketed liquid roots (mix_solver_sm.hpp)
+template <bool DEW, bool ROBUST>
 __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const double* __restrict__ params,
                                                              const double* __restrict__ kij,
                                                              const double* __restrict__ temp,
@@ -203,7 +209,8 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
 #ifdef PCS_MIX_DIAG
         long long t0 = clock64();
 #endif
-        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
+        int rc = ROBUST ? bubble_dew_solve_sm<DEW, MixModel, true>(m, z[i], p_init[i] / (T * P_UNIT), r)
+                        : PCS_BD_SOLVE<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
 #ifdef PCS_MIX_DIAG
 #if PCS_MIX_DIAG == 3
         r.iters |= (1 << 30);
@@ -227,6 +234,8 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
 // control block (int32, after perm[n] in the workspace): [0..8] class counts -> offsets, [16] queue head
 // ------------------------------------------------------------------------------------------
 constexpr int QCTRL_HEAD = 16, QCTRL_INTS = 64;
+// the rows the queue kernel gives up on: count at ctrl[QCTRL_INTS] (= retry[0]), entries behind it (the layout of the other
+// two-pass schedules), consumed by k_mix_bubble_dew_retry<DEW, true>
 constexpr int QCHUNK = 64;  // rows a wave reserves per atomic on the queue head
 
 __device__ __forceinline__ int mix_queue_bin(const double* __restrict__ row) { return MIX_BINS - 1 - mix_bucket(row); }
@@ -280,6 +289,7 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
                                                              const int32_t* __restrict__ perm, int32_t* __restrict__ ctrl,
                                                              double* __restrict__ p_out, double* __restrict__ rho4,
                                                              uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
+    int32_t* __restrict__ retry = ctrl + QCTRL_INTS;
     const int lane = threadIdx.x;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int total = (int)n;
@@ -341,7 +351,10 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
             nev++;
             if (L.done()) L.out.iters = (nev & 4095) | ((t_start & 0xffff) << 12);
 #endif
-            if (L.done()) mix_store<DEW>(row, L.rc, L.out, T, p_out, rho4, status, iters);
+            if (L.done()) {
+                mix_store<DEW>(row, L.rc, L.out, T, p_out, rho4, status, iters);  // a failed row: provisional
+                if (L.rc != BD_OK) retry[1 + atomicAdd(&retry[0], 1)] = (int32_t)row;
+            }
         }
     }
 }
@@ -469,7 +482,7 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
         // work-queue schedule: perm[n] + control block in the workspace
         int32_t* perm = static_cast<int32_t*>(workspace);
         int32_t* ctrl = perm + n;
-        if (int ez = zero_ints(ctrl, QCTRL_INTS, s)) return ez;
+        if (int ez = zero_ints(ctrl, QCTRL_INTS + 1, s)) return ez;  // control block + the count of the second-pass list
         const unsigned g256 = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);
         hipLaunchKernelGGL(k_mix_class_scan, dim3(1), dim3(64), 0, s, ctrl);
@@ -478,12 +491,18 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
         unsigned waves = (unsigned)queue_waves();
         const unsigned needed = (unsigned)((n + 63) / 64);
         if (waves > needed) waves = needed;
-        if (dew)
+        const int32_t* list = ctrl + QCTRL_INTS;
+        if (dew) {
             hipLaunchKernelGGL(k_mix_bubble_dew_queue<true>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
                                (const int32_t*)perm, ctrl, p_out, rho4, status, iters);
-        else
+            hipLaunchKernelGGL((k_mix_bubble_dew_retry<true, true>), dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z,
+                               p_init, p_out, rho4, status, iters, list, n);
+        } else {
             hipLaunchKernelGGL(k_mix_bubble_dew_queue<false>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
                                (const int32_t*)perm, ctrl, p_out, rho4, status, iters);
+            hipLaunchKernelGGL((k_mix_bubble_dew_retry<false, true>), dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z,
+                               p_init, p_out, rho4, status, iters, list, n);
+        }
         e = hipGetLastError();
         if (e != hipSuccess) return fail("k_mix_bubble_dew_queue launch", e);
         return 0;
@@ -497,13 +516,13 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
         hipLaunchKernelGGL(k_mix_bubble_dew<true>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
                            rho4, status, iters, retry);
         if (retry)
-            hipLaunchKernelGGL(k_mix_bubble_dew_retry<true>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
+            hipLaunchKernelGGL((k_mix_bubble_dew_retry<true, false>), dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
                                p_out, rho4, status, iters, (const int32_t*)retry, n);
     } else {
         hipLaunchKernelGGL(k_mix_bubble_dew<false>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
                            rho4, status, iters, retry);
         if (retry)
-            hipLaunchKernelGGL(k_mix_bubble_dew_retry<false>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
+            hipLaunchKernelGGL((k_mix_bubble_dew_retry<false, false>), dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
                                p_out, rho4, status, iters, (const int32_t*)retry, n);
     }
     hipError_t e = hipGetLastError();

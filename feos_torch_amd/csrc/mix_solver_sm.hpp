@@ -20,7 +20,14 @@
 namespace pcs {
 
 // Per-lane solver state.  start() -> { point(); e = phase_eval(...); consume(e); } until done().
-template <bool DEW>
+// ROBUST (second pass over the rows the first pass gives up on): every liquid root is BRACKETED before it is refined --
+// hi = the first of eta = 0.5, 0.62, 0.70, 0.78, 0.86 with p > p_spec and dp > 0, lo = the candidate below it (for 0.5: the
+// density is lowered by factors 0.8 until p < p_spec or dp < 0) -- then Newton on the scaled function safeguarded by
+// bisection.  Very cold heavy components (T/Tc < 0.25) need it: above eta = 0.5 their PC-SAFT pressure is neither monotone
+// nor convex and the plain Newton of the first pass jumps over the root into the unstable region.  Judged with the oracle's
+// independent continuation solver (oracle/mix_continuation.hpp, tests/test_mix_missed_gpu.py): of the rows the first pass
+// fails on, the ones that do have a solution are recovered by this pass.
+template <bool DEW, bool ROBUST = false>
 struct BdLane {
     enum : int { S_ROOT, S_SS, S_NEWTON_S, S_NEWTON_N, S_DONE };
     enum : int { R_PURE0, R_PURE1, R_SS, R_BUBBLE };  // who asked for the liquid root
@@ -31,6 +38,8 @@ struct BdLane {
     int r_for, r_it;
     bool r_dense, r_has_alt, r_warm;
     double r_x0, r_x1, r_pk, r_rho, r_pspec, r_palt, r_errprev;
+    int r_phase, r_k;     // ROBUST: 0 = looking for hi among the candidates, 1 = walking down for lo, 2 = safeguarded Newton
+    double r_lo, r_hi;    // ROBUST: bracket of the root
     // dew initialisation
     double f0, x0, x1, p0, rl, xi_prev, res_prev, xi_lo, xi_hi;
     int ss;
@@ -53,8 +62,9 @@ struct BdLane {
         r_pk = m.packing(xa, xb);
         // warm start from the liquid density tracked at the previous composition (re-solves during the substitution);
         // a warm start that misbehaves falls back to the cold one
-        r_warm = rho_start > 0.0 && rho_start * r_pk < 0.7;
+        r_warm = !ROBUST && rho_start > 0.0 && rho_start * r_pk < 0.7;  // warm starts are an optimisation of the first pass
         r_rho = r_warm ? rho_start : 0.5 / r_pk;
+        r_phase = 0; r_k = 0; r_lo = 0.0; r_hi = 0.0;
         r_pspec = pspec;
         r_has_alt = has_alt;
         r_palt = palt;
@@ -95,23 +105,57 @@ struct BdLane {
 #define PCS_SM_START_ROOT_WARM(who, xa, xb, pspec, has_alt, palt, rho0) start_root(m, who, xa, xb, pspec, has_alt, palt, rho0)
         if (stage == S_ROOT) {
             double p = e.p(), dp = r_x0 * e.dp0() + r_x1 * e.dp1();
+            bool bad = false, done = false;
+            double step = 0.0, rho_new = r_rho;
+            if (ROBUST) {
+                bad = !is_finite_bits(p);
+                const bool above = (p > r_pspec) && (dp > 0.0);  // on the liquid branch above the root
+                if (!bad && r_phase == 0) {
+                    if (above) {
+                        r_hi = r_rho;
+                        if (r_k == 0) { r_phase = 1; r_lo = r_rho; r_it = 0; r_rho = 0.8 * r_rho; return; }
+                        r_phase = 2;  // r_lo = the candidate below; this evaluation (at hi) starts the Newton
+                    } else {
+                        r_lo = r_rho;
+                        r_k++;
+                        if (r_k >= 5) bad = true;
+                        else { r_rho = (r_k == 1 ? 0.62 : (r_k == 2 ? 0.70 : (r_k == 3 ? 0.78 : 0.86))) / r_pk; return; }
+                    }
+                } else if (!bad && r_phase == 1) {
+                    if (!above) { r_lo = r_rho; r_phase = 2; r_it = 0; r_rho = 0.5 * (r_lo + r_hi); return; }
+                    r_hi = r_rho;  // still above the root: a tighter hi
+                    if (++r_it >= 12) bad = true;
+                    else { r_rho = 0.8 * r_rho; return; }
+                }
+                if (!bad) {  // phase 2: bracket update, scaled Newton, bisection where Newton leaves the bracket
+                    if (above) r_hi = r_rho; else r_lo = r_rho;
+                    const double den = dp - 4.0 * (p - r_pspec) * r_pk / (1.0 - r_rho * r_pk);
+                    rho_new = (dp > 0.0 && den > 0.0) ? r_rho - (p - r_pspec) / den : -1.0;
+                    const bool newton = rho_new > r_lo && rho_new < r_hi;
+                    if (!newton) rho_new = 0.5 * (r_lo + r_hi);
+                    step = r_rho - rho_new;
+                    done = (newton && fabs(step) <= LIQ_ROOT_TOL * r_rho) || (r_hi - r_lo) <= 1e-12 * r_hi;
+                    r_it++;
+                    if (!done && r_it >= 2 * LIQ_ROOT_MAX_IT) bad = true;
+                }
+            } else {
             if (r_it == 0 && !r_dense && !r_warm && !(p > r_pspec)) {
                 r_rho = 0.62 / r_pk;  // very cold / dense: restart on the dense side (plain Newton from there)
                 r_dense = true;
                 return;
             }
             double den = r_dense ? dp : dp - 4.0 * (p - r_pspec) * r_pk / (1.0 - r_rho * r_pk);
-            bool bad = !(dp > 0.0) || !(den > 0.0) || !is_finite_bits(p);
-            double step = (p - r_pspec) / den;
-            double rho_new = r_rho - step;
+            bad = !(dp > 0.0) || !(den > 0.0) || !is_finite_bits(p);
+            step = (p - r_pspec) / den;
+            rho_new = r_rho - step;
             bad = bad || !(rho_new > 0.0) || !is_finite_bits(rho_new);
-            bool done = false;
             if (!bad) {
                 double err = fabs(step) / r_rho;
                 done = err <= LIQ_ROOT_TOL || (r_it >= 3 && err < 1e-7 && err >= 0.25 * r_errprev);
                 r_errprev = err;
                 r_it++;
                 if (!done && r_it >= LIQ_ROOT_MAX_IT) bad = true;
+            }
             }
             if (bad && r_warm) {  // the warm start left the liquid branch: same root from the cold start
                 PCS_SM_START_ROOT(r_for, r_x0, r_x1, r_pspec, r_has_alt, r_palt);
@@ -308,12 +352,12 @@ struct BdLane {
 constexpr int BD_EVAL_GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MAX_IT + 2) + 2 * NEWTON_MAX_IT + 8;
 
 // One row per lane: every pass of the wave-level loop evaluates once for every unfinished lane.
-template <bool DEW, class Model>
+template <bool DEW, class Model, bool ROBUST = false>
 PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
                                 int newton_max = NEWTON_MAX_IT) {
-    BdLane<DEW> L;
+    BdLane<DEW, ROBUST> L;
     L.start(m, z0, p_init, ss_max, newton_max);
-    for (int guard = 0; guard < BD_EVAL_GUARD; guard++) {
+    for (int guard = 0; guard < (ROBUST ? 3 : 1) * BD_EVAL_GUARD; guard++) {
         if (__ballot(!L.done()) == 0ull) break;
         if (L.done()) continue;
         double e0, e1;

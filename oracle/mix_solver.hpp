@@ -15,6 +15,10 @@
 // (feos_torch/pcsaft_mix.py:443, :467) whose density derivatives vanish at the solution, so it
 // depends on the Helmholtz model only.
 //
+// Two attempts per row, as in the kernels (csrc/mix_solver_sm.hpp): the plain form first; a row it gives up on is solved
+// again with `robust` = bracketed liquid roots (liquid_root_bracketed).  Which failed rows have a solution at all is judged
+// by the independent second solver, mix_continuation.hpp.
+//
 // Model-agnostic: `Model` provides  template<class S> S a(const S& T, const S* rho) const
 // (reduced residual Helmholtz energy density) and  F packing(F T, const F* x)  =
 // zeta3 / rho_total at composition x.  Used for PcSaftMix and GcPcSaftMix.
@@ -67,12 +71,65 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
 // the scaled function is nearly linear).  Only used to initialise the phase-equilibrium Newton, so
 // a relative step of LIQ_ROOT_TOL suffices.  Same logic and caps as csrc/mix_solver.hpp.
 constexpr double LIQ_ROOT_TOL = 1e-3;  // as csrc/mix_solver.hpp
+constexpr double ETA_MAX_LIQ = 0.9;    // as csrc/mix_solver.hpp
 constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
 constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double NEWTON_TRACE = 1e-4, NEWTON_TRACE_MAX = 100.0;
 constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point successive substitution hands over to Newton
+// Robust form of the liquid root (second pass of the solvers, csrc/mix_solver.hpp: ROBUST): a bracket [lo, hi] with
+// p(lo) < p_spec < p(hi), dp(hi) > 0 is established first -- hi = the first of eta = 0.5, 0.62, 0.70, 0.78, 0.86 at which p
+// exceeds p_spec, lo = the candidate below it (or, for eta = 0.5, found by halving the density until p < p_spec or dp < 0) --
+// then Newton on the scaled function, safeguarded by bisection.  Needed for very cold heavy components (T/Tc < 0.25): there
+// the PC-SAFT pressure is not monotone-convex above eta = 0.5 and the plain Newton of the fast form jumps over the root.
 template <class F, class Model>
-bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out, F rho_start = F(0)) {
+bool liquid_root_bracketed(const Model& model, F T, const F* x, F p_spec, F& rho_out) {
+    const F pk = model.packing(T, x);
+    auto ev = [&](F rho, F& p, F& dp) {
+        F r[2] = {x[0] * rho, x[1] * rho};
+        PhaseEval<F> e = eval_phase<F>(model, T, r);
+        p = e.p();
+        dp = x[0] * e.dp(0) + x[1] * e.dp(1);
+    };
+    const double cand[5] = {0.5, 0.62, 0.70, 0.78, 0.86};
+    F lo = F(0), hi = F(0), p, dp;
+    int k = 0;
+    for (; k < 5; k++) {
+        hi = F(cand[k]) / pk;
+        ev(hi, p, dp);
+        if (!(p == p)) return false;
+        if (p > p_spec && dp > 0) break;
+        lo = hi;
+    }
+    if (k == 5) return false;
+    if (k == 0) {  // root below eta = 0.5: walk down to the first point below the root (or into the unstable region)
+        lo = hi;
+        bool found = false;
+        for (int j = 0; j < 12 && !found; j++) {
+            lo = lo * F(0.8);
+            ev(lo, p, dp);
+            if (!(p > p_spec) || !(dp > 0)) found = true;
+        }
+        if (!found) return false;
+    }
+    F rho = hi;
+    for (int it = 0; it < 60; it++) {
+        ev(rho, p, dp);
+        if (!(p == p)) return false;
+        if (p > p_spec && dp > 0) hi = rho; else lo = rho;
+        F den = dp - F(4) * (p - p_spec) * pk / (F(1) - rho * pk);
+        F rho_new = (dp > 0 && den > 0) ? rho - (p - p_spec) / den : F(-1);
+        bool newton = rho_new > lo && rho_new < hi;
+        if (!newton) rho_new = F(0.5) * (lo + hi);
+        F err = (rho_new > rho ? rho_new - rho : rho - rho_new) / rho;
+        rho = rho_new;
+        if ((newton && err <= F(LIQ_ROOT_TOL) * F(1e-3)) || (hi - lo) <= F(1e-12) * hi) { rho_out = rho; return true; }
+    }
+    return false;
+}
+
+template <class F, class Model>
+bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out, F rho_start = F(0), bool robust = false) {
+    if (robust) return liquid_root_bracketed<F>(model, T, x, p_spec, rho_out);  // second pass: no warm starts
     static const bool plain = getenv("ORC_LIQ_PLAIN") != nullptr;
     static const double tol = getenv("ORC_LIQ_TOL") ? atof(getenv("ORC_LIQ_TOL")) : LIQ_ROOT_TOL;
     F pk = model.packing(T, x);
@@ -90,6 +147,9 @@ bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out, F rh
         F den = (dense || plain) ? dp : dp - F(4) * (p - p_spec) * pk / (F(1) - rho * pk);
         F step = (p - p_spec) / den;
         F rho_new = rho - step;
+        // very cold liquids sit above the dense restart point (eta > 0.62): Newton from below overshoots towards the
+        // hard-sphere pole; keep the iterate below eta = ETA_MAX_LIQ by bisecting towards it (as csrc/mix_solver.hpp)
+        if (dense && rho_new * pk > F(ETA_MAX_LIQ)) { rho_new = F(0.5) * (rho + F(ETA_MAX_LIQ) / pk); step = rho - rho_new; }
         if (!(dp > 0) || !(p == p) || !(den > 0) || !(rho_new > 0) || !(rho_new == rho_new)) {
             if (warm) return liquid_root<F>(model, T, x, p_spec, rho_out);
             return false;
@@ -131,13 +191,14 @@ struct MixSolveInfo { int iters; };
 // z = mole fraction of component 1 in the specified phase; p_init [reduced] = caller's initial
 // pressure (src/pcsaft.rs:174 passes it to feos as Some(p)).  Outputs partial densities.
 template <class F, class Model>
-bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, F* rho_inc, MixSolveInfo& info, F tol) {
+bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, F* rho_inc, MixSolveInfo& info, F tol,
+                bool robust = false) {
     F z[2] = {z1, F(1) - z1};
     F rs, ri[2];  // total density of the specified phase, partial densities of the incipient one
     info.iters = 0;
     if (!dew) {
         // liquid at the initial pressure (fallback: zero pressure), ideal vapour at its fugacities
-        if (!liquid_root<F>(model, T, z, p_init, rs) && !liquid_root<F>(model, T, z, F(0), rs)) return false;
+        if (!liquid_root<F>(model, T, z, p_init, rs, F(0), robust) && !liquid_root<F>(model, T, z, F(0), rs, F(0), robust)) return false;
         F r[2] = {z[0] * rs, z[1] * rs};
         PhaseEval<F> e = eval_phase<F>(model, T, r);
         for (int i = 0; i < 2; i++) ri[i] = r[i] * exp(e.g[i]);
@@ -148,7 +209,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         for (int i = 0; i < 2; i++) {
             F xi[2] = {i == 0 ? F(1) : F(0), i == 1 ? F(1) : F(0)};
             F rho0;
-            if (!liquid_root<F>(model, T, xi, F(0), rho0)) { ok = false; break; }
+            if (!liquid_root<F>(model, T, xi, F(0), rho0, F(0), robust)) { ok = false; break; }
             F r[2] = {xi[0] * rho0, xi[1] * rho0};
             PhaseEval<F> e = eval_phase<F>(model, T, r);
             f[i] = rho0 * exp(e.g[i]);
@@ -188,7 +249,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
                 if (!have || attempt == 1) {
                     // a re-solve starts from the tracked density when the evaluation there was usable
                     const F warm_rho = (have && attempt == 1 && fine_prev) ? rl : F(0);
-                    if (!liquid_root<F>(model, T, x, F(0), rl, warm_rho) && !liquid_root<F>(model, T, x, p0, rl)) {
+                    if (!liquid_root<F>(model, T, x, F(0), rl, warm_rho, robust) && !liquid_root<F>(model, T, x, p0, rl, F(0), robust)) {
                         if (getenv("ORC_TRACE")) fprintf(stderr, "FAIL ss-liquid-root ss %d x %.6e %.6e p0 %.6e\n", ss, (double)x[0], (double)x[1], (double)p0);
                         return false;
                     }
@@ -268,7 +329,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             if (dx < F(ss_tol) || narrow) break;
         }
         if (!have) return false;
-        if (!ss_track && !liquid_root<F>(model, T, x, p0, rl) && !liquid_root<F>(model, T, x, F(0), rl)) return false;
+        if (!ss_track && !liquid_root<F>(model, T, x, p0, rl, F(0), robust) && !liquid_root<F>(model, T, x, F(0), rl, F(0), robust)) return false;
         ri[0] = x[0] * rl;
         ri[1] = x[1] * rl;
         rs = p0;  // ideal vapour

@@ -9,6 +9,7 @@
 #include "pcsaft_pure.hpp"
 #include "pcsaft_mix.hpp"
 #include "mix_solver.hpp"
+#include "mix_continuation.hpp"
 #include "gc_pcsaft.hpp"
 
 using namespace oracle;
@@ -316,7 +317,7 @@ void mix_bd_row(const double* par16, const double* kij2, double T, double z, dou
     F rs[2], ri[2];
     MixSolveInfo info;
     F p_red = F(p_pa) / F(T) * F(1.0 / P_UNIT);
-    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol);
+    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol) || bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true);
     *status = ok ? 0 : 1;
     // reference layout (src/pcsaft.rs:225-228): [rhoV_1, rhoV_2, rhoL_1, rhoL_2]
     const F* v = dew ? rs : ri;
@@ -350,6 +351,36 @@ void orc_mix_helmholtz(const double* params, const double* kij, const double* T,
     for (int64_t i = 0; i < n; i++) {
         MixParams<double> q = load_mix<double>(params + 16 * i, kij + 2 * i);
         a[i] = helmholtz_energy_density_mix<double>(q, T[i], rho + 2 * i);
+    }
+}
+
+// The SECOND solver (mix_continuation.hpp): continuation in composition from the pure-component ends.  code [n]:
+// 0 = solution found, 1 = no pure-fluid VLE next to either end, 2 = every route ended in a critical point,
+// 3 = stalled (limit of stability / liquid-liquid region).  rho4 / p_out as orc_mix_bubble_dew; info [n,3] = steps, Newton
+// iterations, route.
+void orc_mix_bubble_dew_continuation(const double* params, const double* kij, const double* T, const double* z, int64_t n,
+                                     int dew, int prec, double* rho4, double* p_out, int32_t* code, int32_t* info) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t i = 0; i < n; i++) {
+        auto run = [&](auto zero) {
+            typedef decltype(zero) F;
+            MixModel<F> model{load_mix<F>(params + 16 * i, kij + 2 * i)};
+            model.q.robust = true;
+            F rs[2] = {0, 0}, ri[2] = {0, 0};
+            ContInfo ci = bubble_dew_continuation<F>(model, F(T[i]), F(z[i]), dew != 0, rs, ri, prec == 1 ? F(1e-15) : F(1e-12));
+            const bool ok = ci.code == CONT_OK;
+            code[i] = ci.code;
+            if (info) { info[3 * i] = ci.steps; info[3 * i + 1] = ci.newton; info[3 * i + 2] = ci.route; }
+            const F* v = dew ? rs : ri;
+            const F* l = dew ? ri : rs;
+            if (rho4) {
+                rho4[4 * i] = ok ? double(v[0]) : 0.0; rho4[4 * i + 1] = ok ? double(v[1]) : 0.0;
+                rho4[4 * i + 2] = ok ? double(l[0]) : 0.0; rho4[4 * i + 3] = ok ? double(l[1]) : 0.0;
+            }
+            if (p_out) p_out[i] = ok ? double(bubble_dew_formula<F>(model.q, F(T[i]), rs, ri)) : 0.0;
+        };
+        if (prec == 1) run((long double)0);
+        else run(double(0));
     }
 }
 
@@ -436,7 +467,7 @@ void gc_bd_row(GcRow& r, double T, double z, double p_pa, bool dew, F tol, doubl
     F rs[2], ri[2];
     MixSolveInfo info;
     F p_red = F(p_pa) / F(T) * F(1.0 / P_UNIT);
-    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol);
+    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol) || bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true);
     *status = ok ? 0 : 1;
     const F* v = dew ? rs : ri;
     const F* l = dew ? ri : rs;

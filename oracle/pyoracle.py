@@ -60,6 +60,7 @@ def lib():
         L.orc_mix_helmholtz.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p]
         L.orc_mix_bubble_dew.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _u8p]
         L.orc_mix_bubble_dew_grad.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p]
+        L.orc_mix_bubble_dew_continuation.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _i32p, _i32p]
         _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
         L.orc_gc_derivatives.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p, _f64p, _f64p]
         L.orc_gc_derivatives.restype = _int
@@ -211,6 +212,21 @@ def mix_bubble_dew(params, kij, T, z, p_init, dew, prec=1):
     st = np.empty(n, dtype=np.uint8)
     lib().orc_mix_bubble_dew(params, kij, T, z, p_init, n, int(bool(dew)), prec, rho4, p, st)
     return p, rho4, st.astype(bool)
+
+
+CONT_CODES = {0: "solution", 1: "no pure-fluid VLE at either end", 2: "curve ends in a critical point", 3: "stalled (stability limit)"}
+
+
+def mix_bubble_dew_continuation(params, kij, T, z, dew, prec=0):
+    """The SECOND, independent bubble / dew solver (oracle/mix_continuation.hpp: continuation in composition from the
+    pure-component ends, bracketed start).  -> p [Pa], rho4 [n,4], code [n] (see CONT_CODES), info [n,3] = (steps, Newton
+    iterations, route)."""
+    params, kij, T, z = _c(params), _c(kij), _c(T), _c(z)
+    n = T.shape[0]
+    rho4, p = np.empty((n, 4)), np.empty(n)
+    code, info = np.empty(n, dtype=np.int32), np.empty((n, 3), dtype=np.int32)
+    lib().orc_mix_bubble_dew_continuation(params, kij, T, z, n, int(bool(dew)), int(prec), rho4, p, code, info)
+    return p, rho4, code, info
 
 
 def mix_bubble_dew_root(params, kij, T, z, p_init, dew, prec=1):
