@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcsaft_hip.so")
+# PCS_HIP_LIB: development aid for A/B runs of variant builds (scripts/dev/mk*.sh -> scratch/ab/lib_<name>.so); still a
+# libpcsaft_hip build, never a fallback
+LIB_PATH = os.environ.get("PCS_HIP_LIB") or os.path.join(_HERE, "libpcsaft_hip.so")
 
 _lib = None
 

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
 #if PCS_MIX_SM
         // a row that fails with the full caps gets the robust second attempt (bracketed liquid roots, mix_solver_sm.hpp):
         // in the second pass, or in place when there is no work list
-        if (!fast && rc != BD_OK) rc = bubble_dew_solve_sm<DEW, GcModelT<double>, true>(m, z[i], p_red, r);
+        if (!fast && rc != BD_OK) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
 #endif
         if (fast && rc != BD_OK) {  // cap hit or failed: the second pass decides
             status[i] = 1;  // provisional

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
     int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, retry ? FAST_SS : SS_MAX_IT, retry ? FAST_NEWTON : NEWTON_MAX_IT);
 #if PCS_MIX_SM
     // single pass without a work list (workspace == NULL): the robust second attempt runs in place
-    if (!retry && rc != BD_OK) rc = bubble_dew_solve_sm<DEW, MixModel, true>(m, z[i], p_red, r);
+    if (!retry && rc != BD_OK) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
 #endif
 #ifdef PCS_MIX_DIAG
 #if PCS_MIX_DIAG == 3
@@ -184,10 +184,9 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
     mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
 }
 
-// K5 second pass over a compacted list (count read on the device).  ROBUST = false: the rows that hit a cap of the fast
-// pass, same arithmetic with the full caps (PCS_MIX_QUEUE = 0 builds).  ROBUST = true: the rows the work-queue kernel gave
-// up on, solved again with bracketed liquid roots (mix_solver_sm.hpp)
-template <bool DEW, bool ROBUST>
+// K5 second pass over a compacted list (count read on the device; PCS_MIX_QUEUE = 0 builds): the rows that hit a cap of the
+// fast pass, same arithmetic with the full caps, then -- as everywhere -- the robust attempt for rows that still fail
+template <bool DEW>
 __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const double* __restrict__ params,
                                                              const double* __restrict__ kij,
                                                              const double* __restrict__ temp,
@@ -209,8 +208,10 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
 #ifdef PCS_MIX_DIAG
         long long t0 = clock64();
 #endif
-        int rc = ROBUST ? bubble_dew_solve_sm<DEW, MixModel, true>(m, z[i], p_init[i] / (T * P_UNIT), r)
-                        : PCS_BD_SOLVE<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
+        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
+#if PCS_MIX_SM
+        if (rc != BD_OK) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r, SS_MAX_IT, NEWTON_MAX_IT, true);
+#endif
 #ifdef PCS_MIX_DIAG
 #if PCS_MIX_DIAG == 3
         r.iters |= (1 << 30);
@@ -234,8 +235,6 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
 // control block (int32, after perm[n] in the workspace): [0..8] class counts -> offsets, [16] queue head
 // ------------------------------------------------------------------------------------------
 constexpr int QCTRL_HEAD = 16, QCTRL_INTS = 64;
-// the rows the queue kernel gives up on: count at ctrl[QCTRL_INTS] (= retry[0]), entries behind it (the layout of the other
-// two-pass schedules), consumed by k_mix_bubble_dew_retry<DEW, true>
 constexpr int QCHUNK = 64;  // rows a wave reserves per atomic on the queue head
 
 __device__ __forceinline__ int mix_queue_bin(const double* __restrict__ row) { return MIX_BINS - 1 - mix_bucket(row); }
@@ -289,7 +288,6 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
                                                              const int32_t* __restrict__ perm, int32_t* __restrict__ ctrl,
                                                              double* __restrict__ p_out, double* __restrict__ rho4,
                                                              uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
-    int32_t* __restrict__ retry = ctrl + QCTRL_INTS;
     const int lane = threadIdx.x;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int total = (int)n;
@@ -346,15 +344,21 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
             L.point(e0, e1);
             PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
             L.consume(m, e);
-            if (++evals > BD_EVAL_GUARD && !L.done()) L.idle();  // rc = BD_FAILED
+            // evaluation budget: BD_EVAL_GUARD bounds the plain form; the robust second attempt gets ROBUST_EVAL_BUDGET (rows it
+            // recovers need < 100; rows without a solution would otherwise run 200-350 evaluations each and, being few and
+            // late, make up the tail of the kernel)
+            if (++evals > (L.robust ? ROBUST_EVAL_BUDGET : BD_EVAL_GUARD) && !L.done()) L.idle();  // rc = BD_FAILED
 #if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
             nev++;
             if (L.done()) L.out.iters = (nev & 4095) | ((t_start & 0xffff) << 12);
 #endif
-            if (L.done()) {
-                mix_store<DEW>(row, L.rc, L.out, T, p_out, rho4, status, iters);  // a failed row: provisional
-                if (L.rc != BD_OK) retry[1 + atomicAdd(&retry[0], 1)] = (int32_t)row;
+            if (L.done() && L.rc != BD_OK && !L.robust) {
+                // the plain form gave the row up: second attempt with bracketed liquid roots, in place (the lane keeps the
+                // row and its coefficients; the other lanes of the wave go on with theirs)
+                L.start(m, z[row], p_init[row] / (T * P_UNIT), SS_MAX_IT, NEWTON_MAX_IT, true);
+                evals = 0;
             }
+            if (L.done()) mix_store<DEW>(row, L.rc, L.out, T, p_out, rho4, status, iters);
         }
     }
 }
@@ -482,7 +486,7 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
         // work-queue schedule: perm[n] + control block in the workspace
         int32_t* perm = static_cast<int32_t*>(workspace);
         int32_t* ctrl = perm + n;
-        if (int ez = zero_ints(ctrl, QCTRL_INTS + 1, s)) return ez;  // control block + the count of the second-pass list
+        if (int ez = zero_ints(ctrl, QCTRL_INTS, s)) return ez;
         const unsigned g256 = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);
         hipLaunchKernelGGL(k_mix_class_scan, dim3(1), dim3(64), 0, s, ctrl);
@@ -491,18 +495,12 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
         unsigned waves = (unsigned)queue_waves();
         const unsigned needed = (unsigned)((n + 63) / 64);
         if (waves > needed) waves = needed;
-        const int32_t* list = ctrl + QCTRL_INTS;
-        if (dew) {
+        if (dew)
             hipLaunchKernelGGL(k_mix_bubble_dew_queue<true>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
                                (const int32_t*)perm, ctrl, p_out, rho4, status, iters);
-            hipLaunchKernelGGL((k_mix_bubble_dew_retry<true, true>), dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z,
-                               p_init, p_out, rho4, status, iters, list, n);
-        } else {
+        else
             hipLaunchKernelGGL(k_mix_bubble_dew_queue<false>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
                                (const int32_t*)perm, ctrl, p_out, rho4, status, iters);
-            hipLaunchKernelGGL((k_mix_bubble_dew_retry<false, true>), dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z,
-                               p_init, p_out, rho4, status, iters, list, n);
-        }
         e = hipGetLastError();
         if (e != hipSuccess) return fail("k_mix_bubble_dew_queue launch", e);
         return 0;
@@ -516,13 +514,13 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
         hipLaunchKernelGGL(k_mix_bubble_dew<true>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
                            rho4, status, iters, retry);
         if (retry)
-            hipLaunchKernelGGL((k_mix_bubble_dew_retry<true, false>), dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
+            hipLaunchKernelGGL(k_mix_bubble_dew_retry<true>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
                                p_out, rho4, status, iters, (const int32_t*)retry, n);
     } else {
         hipLaunchKernelGGL(k_mix_bubble_dew<false>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
                            rho4, status, iters, retry);
         if (retry)
-            hipLaunchKernelGGL((k_mix_bubble_dew_retry<false, false>), dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
+            hipLaunchKernelGGL(k_mix_bubble_dew_retry<false>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
                                p_out, rho4, status, iters, (const int32_t*)retry, n);
     }
     hipError_t e = hipGetLastError();

@@ -385,9 +385,8 @@ int pcs_abi_version(void) { return 102; }  // 102: pcs_gc_segment_gradient, pcs_
 
 const char* pcs_last_error(void) { return g_err; }
 
-// retry list of the pure / gc two-pass schedules (n + 1 ints), or of the mixture work queue: row order (n) + control block
-// (64) + list of the rows for the robust second pass (n + 1)
-int64_t pcs_workspace_bytes(int64_t n) { return (int64_t)sizeof(int32_t) * (2 * n + 72); }
+// retry list of the pure / gc two-pass schedules (n + 1 ints) or row order + control block of the mixture work queue (n + 64)
+int64_t pcs_workspace_bytes(int64_t n) { return (int64_t)sizeof(int32_t) * (n + 64); }
 
 // stage 1: zero the retry counter and run the fast kernel over all rows
 static int launch_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,

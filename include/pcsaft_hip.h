@@ -34,7 +34,7 @@ int pcs_abi_version(void);
 const char* pcs_last_error(void);
 
 /* Bytes of device scratch a call on n rows needs (retry list of the pure / gc robust pass, or row order +
- * control block of the mixture work queue + the list of rows for its robust second pass). */
+ * control block of the mixture work queue). */
 int64_t pcs_workspace_bytes(int64_t n);
 
 /*

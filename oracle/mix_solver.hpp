@@ -72,6 +72,7 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
 // a relative step of LIQ_ROOT_TOL suffices.  Same logic and caps as csrc/mix_solver.hpp.
 constexpr double LIQ_ROOT_TOL = 1e-3;  // as csrc/mix_solver.hpp
 constexpr double ETA_MAX_LIQ = 0.9;    // as csrc/mix_solver.hpp
+constexpr double STAB_REJECT = -0.5;   // as csrc/mix_solver_sm.hpp: det(M) <= STAB_REJECT |M00 M11| -> unstable liquid
 constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
 constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double NEWTON_TRACE = 1e-4, NEWTON_TRACE_MAX = 100.0;
@@ -201,6 +202,15 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         if (!liquid_root<F>(model, T, z, p_init, rs, F(0), robust) && !liquid_root<F>(model, T, z, F(0), rs, F(0), robust)) return false;
         F r[2] = {z[0] * rs, z[1] * rs};
         PhaseEval<F> e = eval_phase<F>(model, T, r);
+        if (robust) {
+            // the specified liquid must be diffusionally stable (as csrc/mix_solver_sm.hpp): 98 % of the rows that fail are
+            // liquids inside a liquid-liquid spinodal, for which the bubble curve has no branch through this composition
+            F m00 = F(1) / r[0] + e.h[0][0], m11 = F(1) / r[1] + e.h[1][1];
+            static const double thr = getenv("ORC_STAB_THRESH") ? atof(getenv("ORC_STAB_THRESH")) : STAB_REJECT;
+            F am = m00 * m11;
+            if (am < 0) am = -am;
+            if (!(m00 * m11 - e.h[0][1] * e.h[0][1] > F(thr) * am)) return false;
+        }
         for (int i = 0; i < 2; i++) ri[i] = r[i] * exp(e.g[i]);
     } else {
         // Raoult: zero-pressure pure-liquid fugacities f_i, p = 1/sum(y_i/f_i), x_i = y_i p/f_i

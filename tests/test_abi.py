@@ -34,7 +34,7 @@ def test_binding_table_matches_header(hip_lib):
 def test_abi_version_and_error_string(hip_lib):
     assert hip_lib.pcs_abi_version() >= 100
     assert hip_lib.pcs_last_error() == b""
-    assert hip_lib.pcs_workspace_bytes(1000) == 4 * (2 * 1000 + 72)  # row order + control block + second-pass list
+    assert hip_lib.pcs_workspace_bytes(1000) == 4 * (1000 + 64)  # row order / retry list + control block
 
 
 def test_argument_validation_without_gpu(hip_lib):
