@@ -153,11 +153,14 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
         MixResult r;
         const double p_red = p_init[i] / (T * P_UNIT);
         const bool fast = !RETRY && retry;
-        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT);
 #if PCS_MIX_SM
-        // a row that fails with the full caps gets the robust second attempt (bracketed liquid roots, mix_solver_sm.hpp):
-        // in the second pass, or in place when there is no work list
-        if (!fast && rc != BD_OK) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
+        bool root_failed = false;
+        int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT, false, &root_failed);
+        // a row that fails at a liquid root with the full caps gets the robust second attempt (bracketed liquid roots,
+        // mix_solver_sm.hpp): in the second pass, or in place when there is no work list
+        if (!fast && rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
+#else
+        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT);
 #endif
         if (fast && rc != BD_OK) {  // cap hit or failed: the second pass decides
             status[i] = 1;  // provisional

@@ -63,6 +63,9 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
 #ifndef PCS_MIX_QUEUE
 #define PCS_MIX_QUEUE 1  // 1: class-ordered work queue with persistent waves, 0: fast pass + retry pass
 #endif
+#ifndef PCS_INPLACE_ROBUST
+#define PCS_INPLACE_ROBUST 1  // 0 (A/B builds): the work-queue kernel does not restart failed rows
+#endif
 #ifndef PCS_REFILL_MIN
 #define PCS_REFILL_MIN 8  // lanes that must be idle before the wave refills (A/B dew 1e6 rows: 1: 7.9 ms, 4: 7.7, 8: 7.5, 16: 7.8)
 #endif
@@ -161,10 +164,13 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
 #ifdef PCS_MIX_DIAG
     long long t0 = clock64();
 #endif
-    int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, retry ? FAST_SS : SS_MAX_IT, retry ? FAST_NEWTON : NEWTON_MAX_IT);
 #if PCS_MIX_SM
+    bool root_failed = false;
+    int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, retry ? FAST_SS : SS_MAX_IT, retry ? FAST_NEWTON : NEWTON_MAX_IT, false, &root_failed);
     // single pass without a work list (workspace == NULL): the robust second attempt runs in place
-    if (!retry && rc != BD_OK) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
+    if (!retry && rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
+#else
+    int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, retry ? FAST_SS : SS_MAX_IT, retry ? FAST_NEWTON : NEWTON_MAX_IT);
 #endif
 #ifdef PCS_MIX_DIAG
 #if PCS_MIX_DIAG == 3
@@ -208,9 +214,12 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
 #ifdef PCS_MIX_DIAG
         long long t0 = clock64();
 #endif
-        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
 #if PCS_MIX_SM
-        if (rc != BD_OK) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r, SS_MAX_IT, NEWTON_MAX_IT, true);
+        bool root_failed = false;
+        int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r, SS_MAX_IT, NEWTON_MAX_IT, false, &root_failed);
+        if (rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r, SS_MAX_IT, NEWTON_MAX_IT, true);
+#else
+        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
 #endif
 #ifdef PCS_MIX_DIAG
 #if PCS_MIX_DIAG == 3
@@ -344,17 +353,17 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
             L.point(e0, e1);
             PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
             L.consume(m, e);
-            // evaluation budget: BD_EVAL_GUARD bounds the plain form; the robust second attempt gets ROBUST_EVAL_BUDGET (rows it
-            // recovers need < 100; rows without a solution would otherwise run 200-350 evaluations each and, being few and
-            // late, make up the tail of the kernel)
-            if (++evals > (L.robust ? ROBUST_EVAL_BUDGET : BD_EVAL_GUARD) && !L.done()) L.idle();  // rc = BD_FAILED
+            // evaluation budget: BD_EVAL_GUARD bounds the plain form, robust_eval_budget the second attempt (mix_solver_sm.hpp)
+            if (++evals >= (L.robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD) && !L.done()) L.idle();  // rc = BD_FAILED
 #if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
             nev++;
             if (L.done()) L.out.iters = (nev & 4095) | ((t_start & 0xffff) << 12);
 #endif
-            if (L.done() && L.rc != BD_OK && !L.robust) {
-                // the plain form gave the row up: second attempt with bracketed liquid roots, in place (the lane keeps the
-                // row and its coefficients; the other lanes of the wave go on with theirs)
+            if (PCS_INPLACE_ROBUST && L.done() && L.rc != BD_OK && !L.robust && L.root_failed) {
+                // the plain form gave the row up at a liquid root: second attempt with bracketed liquid roots, in place (the
+                // lane keeps the row and its coefficients; the other lanes of the wave go on with theirs).  Rows that fail in
+                // the Newton with sound roots (98 % of the failing bubble rows: unstable liquids) are not repeated: the
+                // robust form differs in the roots only, and every repeated row is a potential tail of the kernel
                 L.start(m, z[row], p_init[row] / (T * P_UNIT), SS_MAX_IT, NEWTON_MAX_IT, true);
                 evals = 0;
             }

@@ -24,10 +24,16 @@
 namespace pcs {
 
 constexpr double STAB_REJECT = -0.5;  // see BdLane::consume, R_BUBBLE
-#ifndef PCS_ROBUST_EVAL_BUDGET
-#define PCS_ROBUST_EVAL_BUDGET 128
+// evaluations a robust second attempt may use (all drivers).  Rows it recovers need a bracketed root (~8) + a few Newton
+// iterations (bubble) resp. two pure roots + ~5 sweeps + ~8 Newton iterations (dew); rows without a solution would run
+// 200-350 evaluations each and, being few and scattered, make up the tail of the work-queue kernel
+#ifndef PCS_ROBUST_BUDGET_BUBBLE
+#define PCS_ROBUST_BUDGET_BUBBLE 48
 #endif
-constexpr int ROBUST_EVAL_BUDGET = PCS_ROBUST_EVAL_BUDGET;  // evaluations of a robust second attempt (all drivers)
+#ifndef PCS_ROBUST_BUDGET_DEW
+#define PCS_ROBUST_BUDGET_DEW 96
+#endif
+template <bool DEW> constexpr int robust_eval_budget() { return DEW ? PCS_ROBUST_BUDGET_DEW : PCS_ROBUST_BUDGET_BUBBLE; }
 
 // Per-lane solver state.  start() -> { point(); e = phase_eval(...); consume(e); } until done().
 // `robust` (second attempt on a row the plain form gives up on; a run-time flag of the lane so that a persistent wave can
@@ -42,6 +48,7 @@ constexpr int ROBUST_EVAL_BUDGET = PCS_ROBUST_EVAL_BUDGET;  // evaluations of a 
 template <bool DEW>
 struct BdLane {
     bool robust;
+    bool root_failed;  // a cold liquid root of this attempt failed: the only kind of failure the robust form can repair
     enum : int { S_ROOT, S_SS, S_NEWTON_S, S_NEWTON_N, S_DONE };
     enum : int { R_PURE0, R_PURE1, R_SS, R_BUBBLE };  // who asked for the liquid root
     int stage, rc;
@@ -91,6 +98,7 @@ struct BdLane {
     PCS_DEV void start(const Model& m, double z0_, double p_init_, int ss_max_ = SS_MAX_IT, int newton_max_ = NEWTON_MAX_IT,
                        bool robust_ = false) {
         robust = robust_;
+        root_failed = false;
         z0 = z0_; z1 = 1.0 - z0_; p_init = p_init_;
         ss_max = ss_max_; newton_max = newton_max_;
         rc = BD_FAILED;
@@ -177,8 +185,13 @@ struct BdLane {
                 return;
             }
             if (bad) {
+                root_failed = true;
                 if (r_has_alt) {  // second choice of the specified pressure
                     PCS_SM_START_ROOT(r_for, r_x0, r_x1, r_palt, false, 0.0);
+                } else if (!robust && (r_for == R_PURE0 || r_for == R_PURE1)) {
+                    // plain form: a pure-liquid root that the plain Newton cannot find (very cold component) -- give the row
+                    // to the robust form at once instead of iterating from an uninformed start
+                    stage = S_DONE;  // rc = BD_FAILED
                 } else if (r_for == R_PURE0 || r_for == R_PURE1) {
                     // no Raoult estimate: start the substitution from the vapour composition at the caller's pressure
                     p0 = p_init; x0 = z0; x1 = z1;
@@ -375,12 +388,13 @@ struct BdLane {
 constexpr int BD_EVAL_GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MAX_IT + 2) + 2 * NEWTON_MAX_IT + 8;
 
 // One row per lane: every pass of the wave-level loop evaluates once for every unfinished lane.
+// Two attempts: the plain form, then -- only if one of its liquid roots failed -- the robust form (try_robust).
 template <bool DEW, class Model>
 PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
-                                int newton_max = NEWTON_MAX_IT, bool robust = false) {
+                                int newton_max = NEWTON_MAX_IT, bool robust = false, bool* root_failed = nullptr) {
     BdLane<DEW> L;
     L.start(m, z0, p_init, ss_max, newton_max, robust);
-    for (int guard = 0; guard < (robust ? ROBUST_EVAL_BUDGET : BD_EVAL_GUARD); guard++) {
+    for (int guard = 0; guard < (robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD); guard++) {
         if (__ballot(!L.done()) == 0ull) break;
         if (L.done()) continue;
         double e0, e1;
@@ -389,6 +403,7 @@ PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixRes
         L.consume(m, e);
     }
     out = L.out;
+    if (root_failed) *root_failed = L.root_failed;
     return L.done() ? L.rc : BD_FAILED;
 }
 

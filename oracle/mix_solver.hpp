@@ -84,6 +84,9 @@ constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point su
 // the PC-SAFT pressure is not monotone-convex above eta = 0.5 and the plain Newton of the fast form jumps over the root.
 template <class F, class Model>
 bool liquid_root_bracketed(const Model& model, F T, const F* x, F p_spec, F& rho_out) {
+    // restated 1:1 from the `robust` branch of BdLane::consume, stage S_ROOT (csrc/mix_solver_sm.hpp): same candidates, same
+    // bracket updates, same order of evaluations -- on rows whose pressure is not monotone inside the bracket the root that
+    // is found depends on them
     const F pk = model.packing(T, x);
     auto ev = [&](F rho, F& p, F& dp) {
         F r[2] = {x[0] * rho, x[1] * rho};
@@ -92,38 +95,41 @@ bool liquid_root_bracketed(const Model& model, F T, const F* x, F p_spec, F& rho
         dp = x[0] * e.dp(0) + x[1] * e.dp(1);
     };
     const double cand[5] = {0.5, 0.62, 0.70, 0.78, 0.86};
-    F lo = F(0), hi = F(0), p, dp;
-    int k = 0;
-    for (; k < 5; k++) {
-        hi = F(cand[k]) / pk;
-        ev(hi, p, dp);
-        if (!(p == p)) return false;
-        if (p > p_spec && dp > 0) break;
-        lo = hi;
-    }
-    if (k == 5) return false;
-    if (k == 0) {  // root below eta = 0.5: walk down to the first point below the root (or into the unstable region)
-        lo = hi;
-        bool found = false;
-        for (int j = 0; j < 12 && !found; j++) {
-            lo = lo * F(0.8);
-            ev(lo, p, dp);
-            if (!(p > p_spec) || !(dp > 0)) found = true;
-        }
-        if (!found) return false;
-    }
-    F rho = hi;
-    for (int it = 0; it < 60; it++) {
+    F lo = F(0), hi = F(0), p, dp, rho = F(cand[0]) / pk;
+    int phase = 0, k = 0, it = 0;
+    for (int guard = 0; guard < 200; guard++) {
         ev(rho, p, dp);
         if (!(p == p)) return false;
-        if (p > p_spec && dp > 0) hi = rho; else lo = rho;
+        const bool above = (p > p_spec) && (dp > 0);
+        if (phase == 0) {
+            if (above) {
+                hi = rho;
+                if (k == 0) { phase = 1; lo = rho; it = 0; rho = F(0.8) * rho; continue; }
+                phase = 2;
+            } else {
+                lo = rho;
+                if (++k >= 5) return false;
+                rho = F(cand[k]) / pk;
+                continue;
+            }
+        } else if (phase == 1) {
+            if (!above) { lo = rho; phase = 2; it = 0; rho = F(0.5) * (lo + hi); continue; }
+            hi = rho;
+            if (++it >= 12) return false;
+            rho = F(0.8) * rho;
+            continue;
+        }
+        if (above) hi = rho; else lo = rho;
         F den = dp - F(4) * (p - p_spec) * pk / (F(1) - rho * pk);
         F rho_new = (dp > 0 && den > 0) ? rho - (p - p_spec) / den : F(-1);
-        bool newton = rho_new > lo && rho_new < hi;
+        const bool newton = rho_new > lo && rho_new < hi;
         if (!newton) rho_new = F(0.5) * (lo + hi);
-        F err = (rho_new > rho ? rho_new - rho : rho - rho_new) / rho;
+        F step = rho - rho_new;
+        const bool done = (newton && (step < 0 ? -step : step) <= F(LIQ_ROOT_TOL) * rho) || (hi - lo) <= F(1e-12) * hi;
+        it++;
         rho = rho_new;
-        if ((newton && err <= F(LIQ_ROOT_TOL) * F(1e-3)) || (hi - lo) <= F(1e-12) * hi) { rho_out = rho; return true; }
+        if (done) { rho_out = rho; return true; }
+        if (it >= 60) return false;
     }
     return false;
 }
@@ -187,7 +193,10 @@ bool solve3(F J[3][3], const F* b, F* x) {  // Gaussian elimination with partial
     return true;
 }
 
-struct MixSolveInfo { int iters; };
+struct MixSolveInfo {
+    int iters;
+    bool root_failed = false;  // a cold liquid root of this attempt failed (the only failure the robust attempt repairs)
+};
 
 // z = mole fraction of component 1 in the specified phase; p_init [reduced] = caller's initial
 // pressure (src/pcsaft.rs:174 passes it to feos as Some(p)).  Outputs partial densities.
@@ -199,7 +208,10 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
     info.iters = 0;
     if (!dew) {
         // liquid at the initial pressure (fallback: zero pressure), ideal vapour at its fugacities
-        if (!liquid_root<F>(model, T, z, p_init, rs, F(0), robust) && !liquid_root<F>(model, T, z, F(0), rs, F(0), robust)) return false;
+        if (!liquid_root<F>(model, T, z, p_init, rs, F(0), robust)) {
+            info.root_failed = true;
+            if (!liquid_root<F>(model, T, z, F(0), rs, F(0), robust)) return false;
+        }
         F r[2] = {z[0] * rs, z[1] * rs};
         PhaseEval<F> e = eval_phase<F>(model, T, r);
         if (robust) {
@@ -219,7 +231,12 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         for (int i = 0; i < 2; i++) {
             F xi[2] = {i == 0 ? F(1) : F(0), i == 1 ? F(1) : F(0)};
             F rho0;
-            if (!liquid_root<F>(model, T, xi, F(0), rho0, F(0), robust)) { ok = false; break; }
+            if (!liquid_root<F>(model, T, xi, F(0), rho0, F(0), robust)) {
+                info.root_failed = true;
+                if (!robust) return false;  // plain form: straight to the robust attempt (as csrc/mix_solver_sm.hpp)
+                ok = false;
+                break;
+            }
             F r[2] = {xi[0] * rho0, xi[1] * rho0};
             PhaseEval<F> e = eval_phase<F>(model, T, r);
             f[i] = rho0 * exp(e.g[i]);
@@ -259,7 +276,9 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
                 if (!have || attempt == 1) {
                     // a re-solve starts from the tracked density when the evaluation there was usable
                     const F warm_rho = (have && attempt == 1 && fine_prev) ? rl : F(0);
-                    if (!liquid_root<F>(model, T, x, F(0), rl, warm_rho, robust) && !liquid_root<F>(model, T, x, p0, rl, F(0), robust)) {
+                    bool root_ok = liquid_root<F>(model, T, x, F(0), rl, warm_rho, robust);
+                    if (!root_ok) { info.root_failed = true; root_ok = liquid_root<F>(model, T, x, p0, rl, F(0), robust); }
+                    if (!root_ok) {
                         if (getenv("ORC_TRACE")) fprintf(stderr, "FAIL ss-liquid-root ss %d x %.6e %.6e p0 %.6e\n", ss, (double)x[0], (double)x[1], (double)p0);
                         return false;
                     }

@@ -317,7 +317,7 @@ void mix_bd_row(const double* par16, const double* kij2, double T, double z, dou
     F rs[2], ri[2];
     MixSolveInfo info;
     F p_red = F(p_pa) / F(T) * F(1.0 / P_UNIT);
-    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol) || bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true);
+    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol) || (info.root_failed && bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true));
     *status = ok ? 0 : 1;
     // reference layout (src/pcsaft.rs:225-228): [rhoV_1, rhoV_2, rhoL_1, rhoL_2]
     const F* v = dew ? rs : ri;
@@ -467,7 +467,7 @@ void gc_bd_row(GcRow& r, double T, double z, double p_pa, bool dew, F tol, doubl
     F rs[2], ri[2];
     MixSolveInfo info;
     F p_red = F(p_pa) / F(T) * F(1.0 / P_UNIT);
-    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol) || bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true);
+    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol) || (info.root_failed && bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true));
     *status = ok ? 0 : 1;
     const F* v = dew ? rs : ri;
     const F* l = dew ? ri : rs;

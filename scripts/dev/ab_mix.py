@@ -9,7 +9,7 @@ d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 Pd, Kd, Td, Xd, PId = d(P), d(K), d(T), d(X), d(PI)
 vp = ctypes.c_void_p
 p = torch.empty(n, dtype=torch.float64, device="cuda"); rho4 = torch.empty((n,4), dtype=torch.float64, device="cuda")
-st = torch.empty(n, dtype=torch.uint8, device="cuda"); ws = torch.empty(n+1, dtype=torch.int32, device="cuda")
+st = torch.empty(n, dtype=torch.uint8, device="cuda"); ws = torch.empty(n+64, dtype=torch.int32, device="cuda")  # row order + control block (pcs_workspace_bytes)
 libs = {}
 for nm in names:
     L = ctypes.CDLL(os.path.abspath(f"scratch/ab/lib_{nm}.so"))
@@ -25,4 +25,4 @@ for rnd in range(4):
             e0.record(); run(libs[nm], dew); e1.record(); torch.cuda.synchronize()
             if rnd: res.setdefault((nm, dew), []).append(e0.elapsed_time(e1))
 for nm in names:
-    print(nm, "bubble %.1f ms" % np.median(res[(nm,0)]), "dew %.1f ms" % np.median(res[(nm,1)]), "fails", int(st.sum()))
+    print(nm, "bubble %.2f ms" % np.median(res[(nm,0)]), "dew %.2f ms" % np.median(res[(nm,1)]), "fails", int(st.sum()))
