@@ -172,6 +172,11 @@ struct BdLane {
             step = (p - r_pspec) / den;
             rho_new = r_rho - step;
             bad = bad || !(rho_new > 0.0) || !is_finite_bits(rho_new);
+            // dense restart: the root is bracketed by eta = 0.5 (p < p_spec) and 0.62 (p > p_spec).  An iterate that leaves
+            // that interval is on its way to ANOTHER liquid-like root of a very cold fluid (the pressure is not monotone up
+            // there); which one the plain Newton would land on is a matter of luck, so the row goes to the robust form, whose
+            // systematic search always takes the first bracket above eta = 0.5
+            bad = bad || (r_dense && !(rho_new * r_pk > 0.5 && rho_new * r_pk < 0.62));
             if (!bad) {
                 double err = fabs(step) / r_rho;
                 done = err <= LIQ_ROOT_TOL || (r_it >= 3 && err < 1e-7 && err >= 0.25 * r_errprev);

@@ -71,7 +71,6 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
 // the scaled function is nearly linear).  Only used to initialise the phase-equilibrium Newton, so
 // a relative step of LIQ_ROOT_TOL suffices.  Same logic and caps as csrc/mix_solver.hpp.
 constexpr double LIQ_ROOT_TOL = 1e-3;  // as csrc/mix_solver.hpp
-constexpr double ETA_MAX_LIQ = 0.9;    // as csrc/mix_solver.hpp
 constexpr double STAB_REJECT = -0.5;   // as csrc/mix_solver_sm.hpp: det(M) <= STAB_REJECT |M00 M11| -> unstable liquid
 constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
 constexpr double NEWTON_PROGRESS = 0.9;
@@ -154,10 +153,10 @@ bool liquid_root(const Model& model, F T, const F* x, F p_spec, F& rho_out, F rh
         F den = (dense || plain) ? dp : dp - F(4) * (p - p_spec) * pk / (F(1) - rho * pk);
         F step = (p - p_spec) / den;
         F rho_new = rho - step;
-        // very cold liquids sit above the dense restart point (eta > 0.62): Newton from below overshoots towards the
-        // hard-sphere pole; keep the iterate below eta = ETA_MAX_LIQ by bisecting towards it (as csrc/mix_solver.hpp)
-        if (dense && rho_new * pk > F(ETA_MAX_LIQ)) { rho_new = F(0.5) * (rho + F(ETA_MAX_LIQ) / pk); step = rho - rho_new; }
-        if (!(dp > 0) || !(p == p) || !(den > 0) || !(rho_new > 0) || !(rho_new == rho_new)) {
+        // dense restart: an iterate that leaves (0.5, 0.62) is on its way to another liquid-like root -> robust form
+        // (as csrc/mix_solver_sm.hpp)
+        const bool left = dense && !(rho_new * pk > F(0.5) && rho_new * pk < F(0.62));
+        if (left || !(dp > 0) || !(p == p) || !(den > 0) || !(rho_new > 0) || !(rho_new == rho_new)) {
             if (warm) return liquid_root<F>(model, T, x, p_spec, rho_out);
             return false;
         }
