@@ -400,6 +400,41 @@ void orc_mix_bubble_dew(const double* params, const double* kij, const double* T
     }
 }
 
+// PcSaftMix.derivatives in long double with the safeguarded association iterations and the cancellation-free site
+// fractions: the exact values of the model, against which both the kernels and the reference's own fp64 evaluation
+// (orc_mix_derivatives, robust = 0) are measured row by row.
+void orc_mix_derivatives_ld(const double* params, const double* kij, const double* T, const double* rho, int64_t n,
+                            double* a, double* p, double* mu, double* v) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        typedef long double F;
+        MixParams<F> q = load_mix<F>(params + 16 * i, kij + 2 * i);
+        q.robust = true;
+        F r[2] = {F(rho[2 * i]), F(rho[2 * i + 1])}, aa, pp, m2[2], v2[2];
+        derivatives_mix<F>(q, F(T[i]), r, aa, pp, m2, v2);
+        a[i] = double(aa); p[i] = double(pp);
+        for (int k = 0; k < 2; k++) { mu[2 * i + k] = double(m2[k]); v[2 * i + k] = double(v2[k]); }
+    }
+}
+
+// orc_mix_bubble_dew_grad in long double (exact gradient of the reference's formula at the given densities)
+void orc_mix_bubble_dew_grad_ld(const double* params, const double* kij, const double* T, const double* rho4,
+                                int64_t n, int dew, double* value, double* grad) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        typedef DualN<long double, 19> G;
+        G p[16];
+        for (int k = 0; k < 16; k++) p[k] = G::var((long double)params[16 * i + k], k);
+        MixParams<G> q = make_mix_params<G>(p, G::var((long double)kij[2 * i], 16), G::var((long double)kij[2 * i + 1], 17));
+        q.robust = true;
+        G Tg = G::var((long double)T[i], 18);
+        G rv[2] = {G((long double)rho4[4 * i]), G((long double)rho4[4 * i + 1])}, rl[2] = {G((long double)rho4[4 * i + 2]), G((long double)rho4[4 * i + 3])};
+        G r = dew ? bubble_dew_formula<G>(q, Tg, rv, rl) : bubble_dew_formula<G>(q, Tg, rl, rv);
+        value[i] = double(r.re);
+        for (int k = 0; k < 19; k++) grad[19 * i + k] = double(r.eps[k]);
+    }
+}
+
 // Value and gradient of the bubble / dew pressure formula (pcsaft_mix.py:435-444 / :459-468) at
 // FIXED densities rho4 = (rhoV_1, rhoV_2, rhoL_1, rhoL_2): grad[n,19] = d/d(16 parameters
 // [comp0 x 8, comp1 x 8], kij[0], kij[1], T) — what torch reverse mode yields in the reference.
@@ -485,15 +520,16 @@ extern "C" {
 }  // extern "C" (reopened below)
 
 namespace {
-typedef DualN<double, 4> GcG;
-template <class X> struct LiftG;
-template <> struct LiftG<GcG> { static GcG go(const GcG& g) { return g; } };
-template <int N> struct LiftG<HyperDual<GcG, N>> { static HyperDual<GcG, N> go(const GcG& g) { HyperDual<GcG, N> h; h.re = g; return h; } };
-// gradient model: kab[ka,kb], phi_0, phi_1 carried as DualN tangents (direction 0, 1, 2; T is 3)
+template <class X, class G> struct LiftG;
+template <class G> struct LiftG<G, G> { static G go(const G& g) { return g; } };
+template <class G, int N> struct LiftG<HyperDual<G, N>, G> { static HyperDual<G, N> go(const G& g) { HyperDual<G, N> h; h.re = g; return h; } };
+// gradient model: kab[ka,kb], phi_0, phi_1 carried as DualN tangents (direction 0, 1, 2; T is 3); GcG = DualN<double, 4> or,
+// for the exact gradient, DualN<long double, 4>
+template <class GcG>
 struct GcGradModel {
     GcRow r; GcG kv; GcG ph[2]; int ka, kb;
     template <class X> X a(const X& Tt, const X* rho) const {
-        X ks = LiftG<X>::go(kv), p2[2] = {LiftG<X>::go(ph[0]), LiftG<X>::go(ph[1])};
+        X ks = LiftG<X, GcG>::go(kv), p2[2] = {LiftG<X, GcG>::go(ph[0]), LiftG<X, GcG>::go(ph[1])};
         return gc_helmholtz_energy_density<X>(r, Tt, rho, p2, ka, kb, &ks);
     }
 };
@@ -540,22 +576,29 @@ int orc_gc_bubble_dew(int S, const double* seg, const double* kab, const double*
 
 // value and gradient of the bubble/dew formula at fixed densities w.r.t.
 // (kab[ka,kb] (= kab[kb,ka]), phi_0, phi_1, T): grad [n,4]
+// prec = 1: long double (exact gradient of the reference's formula; its fp64 evaluation amplifies rounding on a few
+// ill-conditioned rows)
 void orc_gc_bubble_dew_grad(int S, const double* seg, const double* kab, const double* counts, const double* bonds,
                             const double* phi, const double* T, const double* rho4, int64_t n, int dew, int ka,
-                            int kb, double* value, double* grad) {
+                            int kb, int prec, double* value, double* grad) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; i++) {
-        typedef DualN<double, 4> G;
-        GcRow r;
-        gc_row(r, S, seg, kab, counts, bonds, phi, i);
-        r.robust = true;
-        GcGradModel model{r, G::var(kab[ka * S + kb], 0), {G::var(phi[2 * i], 1), G::var(phi[2 * i + 1], 2)}, ka, kb};
-        G Tg = G::var(T[i], 3);
-        G rv[2] = {G(rho4[4 * i]), G(rho4[4 * i + 1])}, rl[2] = {G(rho4[4 * i + 2]), G(rho4[4 * i + 3])};
-        G pr = dew ? bubble_dew_formula_generic<G>(model, Tg, rv, rl) : bubble_dew_formula_generic<G>(model, Tg, rl, rv);
-        G res = pr * Tg * P_UNIT;
-        value[i] = res.re;
-        for (int k = 0; k < 4; k++) grad[4 * i + k] = res.eps[k];
+        auto run = [&](auto zero) {
+            typedef decltype(zero) F;
+            typedef DualN<F, 4> G;
+            GcRow r;
+            gc_row(r, S, seg, kab, counts, bonds, phi, i);
+            r.robust = true;
+            GcGradModel<G> model{r, G::var(F(kab[ka * S + kb]), 0), {G::var(F(phi[2 * i]), 1), G::var(F(phi[2 * i + 1]), 2)}, ka, kb};
+            G Tg = G::var(F(T[i]), 3);
+            G rv[2] = {G(F(rho4[4 * i])), G(F(rho4[4 * i + 1]))}, rl[2] = {G(F(rho4[4 * i + 2])), G(F(rho4[4 * i + 3]))};
+            G pr = dew ? bubble_dew_formula_generic<G>(model, Tg, rv, rl) : bubble_dew_formula_generic<G>(model, Tg, rl, rv);
+            G res = pr * Tg * F(P_UNIT);
+            value[i] = double(res.re);
+            for (int k = 0; k < 4; k++) grad[4 * i + k] = double(res.eps[k]);
+        };
+        if (prec == 1) run((long double)0);
+        else run(double(0));
     }
 }
 

@@ -60,13 +60,15 @@ def lib():
         L.orc_mix_helmholtz.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p]
         L.orc_mix_bubble_dew.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _u8p]
         L.orc_mix_bubble_dew_grad.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p]
+        L.orc_mix_derivatives_ld.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p, _f64p, _f64p, _f64p]
+        L.orc_mix_bubble_dew_grad_ld.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p]
         L.orc_mix_bubble_dew_continuation.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _i32p, _i32p]
         _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
         L.orc_gc_derivatives.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p, _f64p, _f64p]
         L.orc_gc_derivatives.restype = _int
         L.orc_gc_bubble_dew.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _u8p]
         L.orc_gc_bubble_dew.restype = _int
-        L.orc_gc_bubble_dew_grad.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _int, _f64p, _f64p]
+        L.orc_gc_bubble_dew_grad.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _int, _int, _f64p, _f64p]
         _lib = L
     return _lib
 
@@ -197,6 +199,16 @@ def mix_derivatives(params, kij, T, rho, robust=False):
     return a, p, mu, v
 
 
+def mix_derivatives_exact(params, kij, T, rho):
+    """PcSaftMix.derivatives in long double, safeguarded association iterations, cancellation-free site fractions: the exact
+    values of the model (rounded to double)."""
+    params, kij, T, rho = _c(params), _c(kij), _c(T), _c(rho)
+    n = T.shape[0]
+    a, p, mu, v = np.empty(n), np.empty(n), np.empty((n, 2)), np.empty((n, 2))
+    lib().orc_mix_derivatives_ld(params, kij, T, rho, n, a, p, mu, v)
+    return a, p, mu, v
+
+
 def mix_helmholtz(params, kij, T, rho):
     params, kij, T, rho = _c(params), _c(kij), _c(T), _c(rho)
     a = np.empty(T.shape[0])
@@ -235,12 +247,13 @@ def mix_bubble_dew_root(params, kij, T, z, p_init, dew, prec=1):
     return rho4, st
 
 
-def mix_bubble_dew_grad(params, kij, T, rho4, dew):
-    """value[n], grad[n,19] = d/d(16 params, kij0, kij1, T) at fixed densities."""
+def mix_bubble_dew_grad(params, kij, T, rho4, dew, exact=False):
+    """value[n], grad[n,19] = d/d(16 params, kij0, kij1, T) at fixed densities.  exact=True: long double (the formulas as
+    written cancel in fp64 on strongly associating rows)."""
     params, kij, T, rho4 = _c(params), _c(kij), _c(T), _c(rho4)
     n = T.shape[0]
     val, grad = np.empty(n), np.empty((n, 19))
-    lib().orc_mix_bubble_dew_grad(params, kij, T, rho4, n, int(bool(dew)), val, grad)
+    (lib().orc_mix_bubble_dew_grad_ld if exact else lib().orc_mix_bubble_dew_grad)(params, kij, T, rho4, n, int(bool(dew)), val, grad)
     return val, grad
 
 
@@ -305,14 +318,14 @@ def gc_bubble_dew_root(segment_records, segments, bonds, binary_segment_records,
     return rho4, st
 
 
-def gc_bubble_dew_grad(enc, phi, T, rho4, dew, s1, s2):
-    """value[n], grad[n,4] = d/d(kab[s1,s2], phi_0, phi_1, T) at fixed densities."""
+def gc_bubble_dew_grad(enc, phi, T, rho4, dew, s1, s2, exact=False):
+    """value[n], grad[n,4] = d/d(kab[s1,s2], phi_0, phi_1, T) at fixed densities (exact=True: long double)."""
     phi, T, rho4 = _c(phi), _c(T), _c(rho4)
     n = T.shape[0]
     val, grad = np.empty(n), np.empty((n, 4))
     ka, kb = enc["ident"].index(s1), enc["ident"].index(s2)
     lib().orc_gc_bubble_dew_grad(enc["S"], _c(enc["seg"]), _c(enc["kab"]), _c(enc["counts"]), _c(enc["bonds"]), phi, T, rho4,
-                                 n, int(bool(dew)), ka, kb, val, grad)
+                                 n, int(bool(dew)), ka, kb, int(bool(exact)), val, grad)
     return val, grad
 
 

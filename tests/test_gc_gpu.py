@@ -96,17 +96,17 @@ def test_random_rows_vs_oracle(amd, oracle, table, dew):
     assert np.max(np.abs(got[both] / want[both] - 1)) < 1e-9
     # gradients: sum over rows of dp/dk_ab(CH3, CH2), per-row dp/dphi and dp/dT vs the oracle
     p.sum().backward()
-    _, grad = oracle.gc_bubble_dew_grad(enc, b["phi"], b["T"], rho4, dew, "CH3", "CH2")
+    _, grad = oracle.gc_bubble_dew_grad(enc, b["phi"], b["T"], rho4, dew, "CH3", "CH2", exact=True)  # long double
     ik = [k[:2] for k in b["kab_list"]].index(("CH3", "CH2"))
     wk = grad[both, 0].sum()
     assert abs(kab.grad[ik].item() - wk - grad[~nn & st, 0].sum()) < 1e-6 * abs(wk) + 1e-3 * (nn != st).sum()
     gp = phi.grad.numpy()[both]
     scale = np.abs(grad[both, 1:3]).max(axis=1, keepdims=True)
     rel_p = (np.abs(gp - grad[both, 1:3]) / scale).max(axis=1)
-    assert np.quantile(rel_p, 0.995) < 1e-7 and rel_p.max() < 1e-3
+    assert rel_p.max() < 1e-7, rel_p.max()
     gt = T.grad.numpy()[both]
     rel_t = np.abs(gt / grad[both, 3] - 1)
-    assert np.quantile(rel_t, 0.995) < 1e-7 and rel_t.max() < 1e-3  # a few ill-conditioned rows amplify 1-ulp differences
+    assert rel_t.max() < 1e-7, rel_t.max()  # (round 1 allowed 1e-3 here: that was the fp64 oracle's own rounding on a few rows)
     assert eos.rows.shape[0] == int((~nn).sum()) and eos.phi.shape[0] == int((~nn).sum())
 
 

@@ -41,16 +41,40 @@ def test_derivatives_vs_reference_python(amd, gm):
     assert hd.shape == (14, 1)
 
 
-def test_derivatives_random_vs_oracle(amd, oracle, gm):
+def test_derivatives_random_rows(amd, oracle, gm):
+    """60 seeded rows of the config-4 distribution, row by row:
+      * against the EXACT values of the model (long double, safeguarded association, cancellation-free site fractions) on
+        every row: a, p, mu to 1e-13 of their scale, v to 1e-10;
+      * against the reference's own fp64 output (the golden vectors, tests/test_pcsaft_mix.py:119-124 tolerances abs 1e-14 /
+        1e-11) on every row where that output is itself good, i.e. where the golden agrees with the exact values to its
+        tolerance; on the remaining rows (strongly associating: the X_B formula as written cancels, or the association
+        Newton as written runs away) the reference's own error is printed and the kernel must be closer to the exact values
+        than the reference is."""
     g = gm["random"]
     P, K, T, rho = (np.array(g[k]) for k in ("params", "kij", "T", "rho"))
-    a, p, mu, v = amd.PcSaftMix(_t(P), _t(K)).derivatives(_t(T), _t(rho))
-    # long-double-free check: the safeguarded fp64 oracle (same model, literal formulas)
-    A, Pp, MU, V = oracle.mix_derivatives(P, K, T, rho, robust=True)
-    # strongly associating rows: the reference's self-association formula cancels in fp64 (see
-    # csrc/pure_model.hpp); the kernel's conjugate form is the accurate one -> relative tolerance
-    assert np.max(np.abs(a.numpy() - A) / np.maximum(1e-3, np.abs(A))) < 1e-7
-    assert np.max(np.abs(mu.numpy() - MU) / np.maximum(1.0, np.abs(MU))) < 1e-7
+    a, p, mu, v = (x.numpy() for x in amd.PcSaftMix(_t(P), _t(K)).derivatives(_t(T), _t(rho)))
+    A, Pp, MU, V = oracle.mix_derivatives_exact(P, K, T, rho)
+    sa = np.maximum(np.abs(A), 1e-6)
+    assert np.max(np.abs(a - A) / sa) < 1e-13
+    assert np.max(np.abs(p - Pp) / np.maximum(np.abs(Pp), rho.sum(axis=1))) < 1e-12
+    assert np.max(np.abs(mu - MU) / np.maximum(1.0, np.abs(MU))) < 1e-13
+    assert np.max(np.abs(v / V - 1.0)) < 1e-10
+    ga, gp, gmu, gv = (np.array(g[k]) for k in ("a", "p", "mu", "v"))
+    def row_err(xa, xp, xmu, xv):  # a, p, mu absolute (|mu| ~ 10); v relative (v ~ 1/rho spans 12 decades)
+        return np.maximum.reduce([np.abs(xa - A), np.abs(xp - Pp), np.abs(xmu - MU).max(axis=1), 1e-3 * np.abs(xv / V - 1.0).max(axis=1)])
+
+    ref_err = row_err(ga, gp, gmu, gv)
+    good = np.isfinite(ref_err) & (ref_err < 1e-13)
+    print(f"reference fp64 output good on {good.sum()} of {len(T)} rows; elsewhere its error is up to {np.nanmax(np.where(good, 0, ref_err)):.2e} "
+          f"({(~np.isfinite(ref_err)).sum()} rows NaN)")
+    assert good.sum() >= 55
+    assert np.max(np.abs(a[good] - ga[good])) < 1e-14
+    assert np.max(np.abs(p[good] - gp[good])) < 1e-14
+    assert np.max(np.abs(mu[good] - gmu[good])) < 1e-13
+    assert np.max(np.abs(v[good] / gv[good] - 1.0)) < 1e-10
+    ours = row_err(a, p, mu, v)
+    bad = ~good & np.isfinite(ref_err)
+    assert np.all(ours[bad] <= ref_err[bad])
 
 
 @pytest.mark.parametrize("key,dew", [("test_bubble", False), ("test_dew", True)])
@@ -113,13 +137,13 @@ def test_jacobian_vs_oracle(amd, oracle):
         ok = ~r["status"].cpu().numpy()
         rho4 = r["rho4"].cpu().numpy()
         J = native.mix_jacobian(_t(P).cuda(), _t(K).cuda(), _t(T).cuda(), r["rho4"], dew).cpu().numpy()
-        _, want = oracle.mix_bubble_dew_grad(P[ok], K[ok], T[ok], rho4[ok], dew)
+        # exact gradient of the reference's formula (long double; the formulas as written cancel in fp64 on strongly
+        # associating rows, which is what round 1's 1e-4 allowance was for)
+        _, want = oracle.mix_bubble_dew_grad(P[ok], K[ok], T[ok], rho4[ok], dew, exact=True)
         scale = np.abs(want).max(axis=1, keepdims=True)
         err = np.abs(J[ok] - want) / scale
-        # the oracle differentiates the reference's literal fp64 formulas (cancelling self-association
-        # term) — allow its noise on the strongly associating rows
-        assert np.quantile(err.max(axis=1), 0.99) < 1e-7
-        assert err.max() < 1e-4
+        print(f"{'dew' if dew else 'bubble'} Jacobian vs exact: max {err.max():.2e} q99 {np.quantile(err.max(axis=1), 0.99):.2e}")
+        assert err.max() < 1e-8
 
 
 def test_jacobian_class_order_is_only_a_schedule(amd):
