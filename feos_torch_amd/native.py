@@ -502,3 +502,26 @@ def gc_derivatives_vjp(table, S, rows, phi, temperature, density, g_a=None, g_p=
                                       _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_gc_derivatives_vjp")
     return gseg, jac9, agg
+
+
+def mixn_derivatives(params, temperature, density):
+    """n-component PcSaftMix.derivatives without k_ij: params [n, nc, 8], density [n, nc] -> (a [n], p [n], mu [n,nc], v [n,nc])."""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    if params.dim() != 3 or params.shape[2] != 8 or not 1 <= params.shape[1] <= 6:
+        raise ValueError("parameters must have shape [N, n, 8] with 1 <= n <= 6 components")
+    nc = int(params.shape[1])
+    params = _prep(params, device, (nc, 8))
+    temperature = _prep(temperature, device)
+    density = _prep(density, device, (nc,))
+    n = temperature.shape[0]
+    _same_rows(n, parameters=params, density=density)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        a = torch.empty(n, dtype=_F64, device=device)
+        p = torch.empty(n, dtype=_F64, device=device)
+        mu = torch.empty((n, nc), dtype=_F64, device=device)
+        v = torch.empty((n, nc), dtype=_F64, device=device)
+        rc = L.pcs_mixn_derivatives(_lib.ptr(params), _lib.ptr(temperature), _lib.ptr(density), nc, n, _lib.ptr(a), _lib.ptr(p),
+                                    _lib.ptr(mu), _lib.ptr(v), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_mixn_derivatives")
+    return a, p, mu, v

@@ -107,9 +107,21 @@ class PcSaftMix:
         """parameters: [N, 2, 8] float64 (component rows as for PcSaftPure); kij: [N, 2] with
         kij[:,0] = k_ij and kij[:,1] = explicit cross-association energy eps_AiBj/k or 0
         (feos_torch/pcsaft_mix.py:13-29; effectively mandatory in the reference, :141/:477)."""
-        if parameters.dim() != 3 or tuple(parameters.shape[1:]) != (2, 8):
-            raise ValueError("parameters must have shape [N, 2, 8] (binary mixtures)")
-        if kij is None:
+        if parameters.dim() != 3 or parameters.shape[2] != 8:
+            raise ValueError("parameters must have shape [N, n, 8]")
+        self.ncomp = int(parameters.shape[1])
+        if self.ncomp != 2:
+            # n-component mixtures (the reference's hs / hc / dispersion / dipole / self-association code is general, :31-154):
+            # state functions only, no k_ij (":75-76 kij can only be used for binary mixtures!"), bubble / dew points are binary
+            if kij is not None:
+                raise Exception("kij can only be used for binary mixtures!")
+            if not 1 <= self.ncomp <= 6:
+                raise ValueError("between 1 and 6 components are supported")
+            if bool((((parameters[:, :, 6] + parameters[:, :, 7]) != 0).sum(dim=1) > 1).any()):
+                raise Exception("Only up to two associating components are allowed, and two only for binary mixtures!")
+            if parameters.requires_grad:
+                raise NotImplementedError("gradients of the n-component state functions are not provided (binary mixtures are)")
+        elif kij is None:
             kij = torch.zeros((parameters.shape[0], 2), dtype=parameters.dtype, device=parameters.device)
         self._set(parameters, kij)
 
@@ -131,7 +143,7 @@ class PcSaftMix:
 
     @property
     def kij_np(self):
-        return self.kij.detach().cpu().numpy()
+        return None if self.kij is None else self.kij.detach().cpu().numpy()
 
     def helmholtz_energy_density(self, temperature, density):
         """a(T, rho_1, rho_2) [A^-3], shape [N, 1] like the reference (:31-154); differentiable."""
@@ -142,16 +154,24 @@ class PcSaftMix:
         (pcs_mix_derivatives_vjp is the backward pass)."""
         temperature = torch.as_tensor(temperature, dtype=torch.float64)
         density = torch.as_tensor(density, dtype=torch.float64)
+        if self.ncomp != 2:
+            a, p, mu, v = native.mixn_derivatives(self._par, temperature, density)
+            dev = self._par.device
+            return a.to(dev), p.to(dev), mu.to(dev), v.to(dev)
         return _MixDerivatives.apply(self._par, self.kij, temperature, density)
 
     def bubble_point(self, temperature, liquid_molefracs, pressure):
         """(p [Pa], nans) at T [K], liquid mole fraction of component 1, initial pressure [Pa] (:422-444)."""
+        if self.ncomp != 2:
+            raise Exception("bubble and dew points are implemented for binary mixtures (src/pcsaft.rs:43-79 takes [N,2,8])")
         value, nans = _BubbleDew.apply(False, self._par, self.kij, temperature, liquid_molefracs, pressure)
         self.reduce(nans)
         return value, nans
 
     def dew_point(self, temperature, vapor_molefracs, pressure):
         """(p [Pa], nans) at T [K], vapour mole fraction of component 1, initial pressure [Pa] (:446-468)."""
+        if self.ncomp != 2:
+            raise Exception("bubble and dew points are implemented for binary mixtures (src/pcsaft.rs:43-79 takes [N,2,8])")
         value, nans = _BubbleDew.apply(True, self._par, self.kij, temperature, vapor_molefracs, pressure)
         self.reduce(nans)
         return value, nans

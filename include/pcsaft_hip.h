@@ -131,6 +131,17 @@ int pcs_mix_derivatives(const double* params, const double* kij, const double* t
                         double* a, double* p, double* mu, double* v, void* stream);
 
 /*
+ * n-component mixtures: PcSaftMix.derivatives for parameters [n, ncomp, 8] WITHOUT k_ij -- the parts of the
+ * reference's model that are written for any number of components (feos_torch/pcsaft_mix.py:31-154: hard sphere, hard chain,
+ * dispersion, dipoles, self association of ONE associating component; "kij can only be used for binary mixtures", :75-76, and two
+ * associating components are binary-only, :250 / :336 -- both stay with pcs_mix_derivatives).
+ *   params [n,ncomp,8], temp [n], rho [n,ncomp] in;  a [n], p [n], mu [n,ncomp], v [n,ncomp] out (each optional); 1 <= ncomp <= 6.
+ * A row with more than one associating component gets NaN in every output (the reference raises).
+ */
+int pcs_mixn_derivatives(const double* params, const double* temp, const double* rho, int ncomp, int64_t n, double* a, double* p,
+                         double* mu, double* v, void* stream);
+
+/*
  * Gradient of the bubble (dew = 0) / dew (dew = 1) pressure [Pa] at the converged densities rho4
  * (from pcs_mix_bubble_dew) — what torch reverse mode through feos_torch/pcsaft_mix.py:435-444 /
  * :459-468 yields.  jac [n,19] = d p / d (params[0,0..7], params[1,0..7], kij[0], kij[1], T).

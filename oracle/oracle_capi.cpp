@@ -10,6 +10,7 @@
 #include "pcsaft_mix.hpp"
 #include "mix_solver.hpp"
 #include "mix_continuation.hpp"
+#include "pcsaft_mixn.hpp"
 #include "gc_pcsaft.hpp"
 
 using namespace oracle;
@@ -398,6 +399,29 @@ void orc_mix_bubble_dew(const double* params, const double* kij, const double* T
             mix_bd_row<double>(params + 16 * i, kij + 2 * i, T[i], z[i], p_init_pa[i], dew != 0, 1e-13,
                                rho4 ? rho4 + 4 * i : nullptr, p_out ? p_out + i : nullptr, status + i);
     }
+}
+
+// n-component PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420 with parameters [n, nc, 8], kij = None): a [n], p [n],
+// mu [n, nc], v [n, nc].  prec = 1: long double.  Returns 1 if a row asks for two associating components (binary only in the
+// reference, :250 / :336) or nc is out of range.
+int orc_mixn_derivatives(const double* params, const double* T, const double* rho, int nc, int64_t n, int prec, double* a,
+                         double* p, double* mu, double* v) {
+    if (nc < 1 || nc > MIXN_MAX) return 1;
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t i = 0; i < n; i++) {
+        auto run = [&](auto zero) {
+            typedef decltype(zero) F;
+            F r[MIXN_MAX], aa, pp, m2[MIXN_MAX], v2[MIXN_MAX];
+            for (int k = 0; k < nc; k++) r[k] = F(rho[nc * i + k]);
+            if (!derivatives_mixn<F>(nc, params + 8 * nc * i, F(T[i]), r, aa, pp, m2, v2)) bad |= 1;
+            a[i] = double(aa); p[i] = double(pp);
+            for (int k = 0; k < nc; k++) { mu[nc * i + k] = double(m2[k]); v[nc * i + k] = double(v2[k]); }
+        };
+        if (prec == 1) run((long double)0);
+        else run(double(0));
+    }
+    return bad;
 }
 
 // PcSaftMix.derivatives in long double with the safeguarded association iterations and the cancellation-free site

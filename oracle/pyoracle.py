@@ -60,6 +60,8 @@ def lib():
         L.orc_mix_helmholtz.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p]
         L.orc_mix_bubble_dew.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _u8p]
         L.orc_mix_bubble_dew_grad.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p]
+        L.orc_mixn_derivatives.argtypes = [_f64p, _f64p, _f64p, _int, _i64, _int, _f64p, _f64p, _f64p, _f64p]
+        L.orc_mixn_derivatives.restype = _int
         L.orc_mix_derivatives_ld.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p, _f64p, _f64p, _f64p]
         L.orc_mix_bubble_dew_grad_ld.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p]
         L.orc_mix_bubble_dew_continuation.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _i32p, _i32p]
@@ -206,6 +208,18 @@ def mix_derivatives_exact(params, kij, T, rho):
     n = T.shape[0]
     a, p, mu, v = np.empty(n), np.empty(n), np.empty((n, 2)), np.empty((n, 2))
     lib().orc_mix_derivatives_ld(params, kij, T, rho, n, a, p, mu, v)
+    return a, p, mu, v
+
+
+def mixn_derivatives(params, T, rho, prec=0):
+    """n-component PcSaftMix.derivatives (parameters [n, nc, 8], kij = None, feos_torch/pcsaft_mix.py:395-420):
+    a [n], p [n], mu [n, nc], v [n, nc].  prec=1: long double."""
+    params, T, rho = _c(params), _c(T), _c(rho)
+    n, nc = rho.shape
+    assert params.shape == (n, nc, 8)
+    a, p, mu, v = np.empty(n), np.empty(n), np.empty((n, nc)), np.empty((n, nc))
+    if lib().orc_mixn_derivatives(params, T, rho, nc, n, int(prec), a, p, mu, v):
+        raise Exception("Only up to two associating components are allowed, and two only for binary mixtures!")
     return a, p, mu, v
 
 

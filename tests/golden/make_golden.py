@@ -190,6 +190,9 @@ if __name__ == "__main__":
     if "gc_seggrad" in which or len(sys.argv) == 1:
         from make_golden_mix import make_gc_seggrad
         make_gc_seggrad(GcPcSaftMix, dump, tl)
+    if "mixn" in which or len(sys.argv) == 1:
+        from make_golden_mix import make_mixn
+        make_mixn(PcSaftMix, dump, tl)
     if "deriv_grad" in which or len(sys.argv) == 1:  # needs pure.json and mix.json (inputs are re-used)
         from make_golden_mix import make_deriv_grad
         make_deriv_grad(PcSaftPure, PcSaftMix, GcPcSaftMix, dump, tl, PURE_TEST_PARAMS)

@@ -310,3 +310,35 @@ def make_deriv_grad(PcSaftPure, PcSaftMix, GcPcSaftMix, dump, tl, pure_test_para
                                             [300.0] * n, [[0.001, 0.002]] * n, rng)
     g["gc"]["test_inputs"]["table"] = [s for s, _ in table]
     dump("deriv_grad.json", g)
+
+
+# ------------------------------------------------------------------------------------------
+# n-component mixtures -> mixn.json
+# The reference's n-component code path cannot actually be run: `kij` must be None for n != 2 (pcsaft_mix.py:75-76) and with
+# kij = None helmholtz_energy_density fails at `self.kij[cross_associating, 1]` (:141) for every n.  What CAN be produced with the
+# unmodified reference is the n = 2 case with kij = 0, on rows with at most one associating component: the n-component code of
+# this repo run at nc = 2 must reproduce it, and for nc > 2 it is pinned by exact properties (tests/test_mixn_gpu.py).
+# ------------------------------------------------------------------------------------------
+def make_mixn(PcSaftMix, dump, tl):
+    rng = np.random.default_rng(61)
+    n, nc = 48, 2
+    P = np.zeros((n, nc, 8))
+    P[:, :, 0] = rng.uniform(1.0, 3.5, (n, nc))
+    P[:, :, 1] = rng.uniform(2.8, 4.2, (n, nc))
+    P[:, :, 2] = rng.uniform(150.0, 350.0, (n, nc))
+    polar = rng.random((n, nc)) < 0.4
+    P[:, :, 3] = np.where(polar, rng.uniform(0.5, 3.0, (n, nc)), 0.0)
+    for r in range(n):  # at most ONE associating component per row, in a third of the rows
+        if r % 3 == 0:
+            c = rng.integers(0, nc)
+            P[r, c, 4] = rng.uniform(0.001, 0.05)
+            P[r, c, 5] = rng.uniform(1000.0, 3000.0)
+            P[r, c, 6], P[r, c, 7] = [(1, 1), (2, 1), (1, 2)][rng.integers(0, 3)]
+    T = rng.uniform(200.0, 450.0, n)
+    d = P[:, :, 1] * (1 - 0.12 * np.exp(-3 * P[:, :, 2] / T[:, None]))
+    x = rng.dirichlet(np.ones(nc), n)
+    eta = np.where(rng.random(n) < 0.5, rng.uniform(0.2, 0.42, n), 10.0 ** rng.uniform(-7, -2, n))
+    rho = x * (eta / (np.pi / 6 * (x * P[:, :, 0] * d**3).sum(axis=1)))[:, None]
+    eos = PcSaftMix(torch.tensor(P, dtype=f64), torch.zeros((n, 2), dtype=f64))
+    a, p, mu, v = eos.derivatives(torch.tensor(T, dtype=f64), torch.tensor(rho, dtype=f64))
+    dump("mixn.json", {"nc2_kij0": {"params": P.tolist(), "T": T.tolist(), "rho": rho.tolist(), "a": tl(a), "p": tl(p), "mu": tl(mu), "v": tl(v)}})
