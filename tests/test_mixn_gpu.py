@@ -104,8 +104,9 @@ def test_one_component_is_the_pure_model(amd):
     a1, p1, dp1 = amd.PcSaftPure(_t(P[:, 0])).derivatives(_t(T), _t(rho[:, 0]))
     assert np.max(np.abs(a.numpy() - a1.numpy()) / np.maximum(np.abs(a1.numpy()), 1e-9)) < 1e-12
     assert np.max(np.abs(p.numpy() - p1.numpy()) / np.maximum(np.abs(p1.numpy()), rho[:, 0])) < 1e-11
-    # v = 1 / (rho dp/drho) for one component
-    assert np.max(np.abs(v[:, 0].numpy() * (rho[:, 0] * dp1.numpy()) - 1.0)) < 1e-9
+    # one component: v = (1 + rho a'') / (rho + rho^2 a'') = 1 / rho, mu = a'
+    assert np.max(np.abs(v[:, 0].numpy() * rho[:, 0] - 1.0)) < 1e-12
+    assert np.max(np.abs((p.numpy() - rho[:, 0] + a.numpy()) / rho[:, 0] - mu[:, 0].numpy())) < 1e-8
 
 
 def test_api_errors(amd):
