@@ -209,6 +209,60 @@ PCS_DEV F2 core_closed_f32(const PureCoefF& c, float rho) {
 }
 #endif
 
+#ifndef PCS_ASSOC_CLOSED
+#define PCS_ASSOC_CLOSED 1
+#endif
+// Association term of a pure component in closed form (value, first and second density derivative).
+//   a_assoc = rho q(S),  q = na (ln XA - XA/2 + 1/2) + nb (ln XB - XB/2 + 1/2),  S = rho Delta(eta) = rho da h(eta),
+//   h = u + 1.5 eta u^2 + 0.5 eta^2 u^3,  u = 1/(1-eta)                                  (pcsaft_pure.py:163-176)
+// XA = 1/(1 + nb S XB), XB = 1/(1 + na S XA) depend on rho through S only.  The association energy is stationary in the
+// site fractions at the mass-action solution (Michelsen's Q function), so
+//   dq/dS = -na nb XA XB,   d2q/dS2 = -na nb (XA' XB + XA XB'),
+//   XA' = alpha (beta S XA - XB) / (1 - alpha beta S^2),  XB' = beta (alpha S XB - XA) / (1 - alpha beta S^2),
+//   alpha = nb XA^2, beta = na XB^2,
+// and a' = q + rho q_S S',  a'' = 2 q_S S' + rho (q_SS S'^2 + q_S S''),  S' = da (h + eta h'),  S'' = da ceta (2 h' + eta h''),
+//   h' = 2.5 u^2 + 4 eta u^3 + 1.5 eta^2 u^4,   h'' = 9 u^3 + 15 eta u^4 + 6 eta^2 u^5.
+// About a third of the generic value/d1/d2 arithmetic of the term (checked against it: tests/test_pure_gpu.py goldens and
+// the 1e6-row parity runs).  XA, XB themselves from the cancellation-free closed forms of pure_model.hpp.
+PCS_DEV F2 assoc_closed_f32(const PureCoefF& c, float rho) {
+    const float eta = rho * c.ceta;
+    const float u = __builtin_amdgcn_rcpf(1.0f - eta);
+    const float u2 = u * u, eu = eta * u;
+    const float h = u * (1.0f + eu * (1.5f + 0.5f * eu));
+    const float h1 = u2 * (2.5f + eu * (4.0f + 1.5f * eu));
+    const float h2 = u2 * u * (9.0f + eu * (15.0f + 6.0f * eu));
+    const float S = rho * c.da * h;
+    const float S1 = c.da * (h + eta * h1);
+    const float S2 = c.da * c.ceta * (2.0f * h1 + eta * h2);
+    const float sa = c.na * S, sb = c.nb * S;  // rho_a Delta, rho_b Delta
+    const float t = sb - sa;
+    const float aux = 1.0f - t;
+    const float sq = __builtin_amdgcn_sqrtf(fmaf(aux, aux, 4.0f * sb));
+    float xa, xb;
+    if (t > 0.5f) {
+        xa = 2.0f * __builtin_amdgcn_rcpf(sq + 1.0f + t);
+        xb = (sq - 1.0f + t) * __builtin_amdgcn_rcpf(2.0f * sb);
+    } else if (t < -0.5f) {
+        xa = (sq - 1.0f - t) * __builtin_amdgcn_rcpf(2.0f * sa);
+        xb = 2.0f * __builtin_amdgcn_rcpf(sq + 1.0f - t);
+    } else {
+        xa = 2.0f * __builtin_amdgcn_rcpf(sq + 1.0f + t);
+        xb = 2.0f * __builtin_amdgcn_rcpf(sq + 1.0f - t);
+    }
+    const float q = c.na * (__logf(xa) - 0.5f * xa + 0.5f) + c.nb * (__logf(xb) - 0.5f * xb + 0.5f);
+    const float nn = c.na * c.nb;
+    const float q1 = -nn * xa * xb;
+    const float al = c.nb * xa * xa, be = c.na * xb * xb;
+    const float rden = __builtin_amdgcn_rcpf(1.0f - al * be * S * S);
+    const float xa1 = al * (be * S * xa - xb) * rden, xb1 = be * (al * S * xb - xa) * rden;
+    const float q2 = -nn * (xa1 * xb + xa * xb1);
+    F2 r;
+    r.v = rho * q;
+    r.d1 = q + rho * q1 * S1;
+    r.d2 = 2.0f * q1 * S1 + rho * (q2 * S1 * S1 + q1 * S2);
+    return r;
+}
+
 // same model as pure_a() (pure_model.hpp), fp32
 PCS_DEV EvalF pure_eval_f32(const PureCoefF& c, float rho) {
 #if PCS_F32_CLOSED
@@ -223,6 +277,9 @@ PCS_DEV EvalF pure_eval_f32(const PureCoefF& c, float rho) {
             a = a + (rho2 * c.qm) * ((J1 * J1) * recipf(J1 - r * J2));
         }
         if (c.assoc) {
+#if PCS_ASSOC_CLOSED
+            a = a + assoc_closed_f32(c, rho);
+#else
             F2 eta_m1 = recipf(1.0f - eta);
             F2 k = eta * eta_m1;
             F2 delta = (((k * ((k * 0.5f) + 1.5f)) + 1.0f) * eta_m1) * c.da;
@@ -242,6 +299,7 @@ PCS_DEV EvalF pure_eval_f32(const PureCoefF& c, float rho) {
                 xb = recipf(sq - t + 1.0f) * 2.0f;
             }
             a = a + rhoa * (logf2(xa) - (xa * 0.5f) + 0.5f) + rhob * (logf2(xb) - (xb * 0.5f) + 0.5f);
+#endif
         }
     }
     EvalF ec;

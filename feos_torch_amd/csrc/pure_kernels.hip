@@ -63,6 +63,12 @@ __device__ __forceinline__ void stage_params(const double* __restrict__ params, 
 #ifndef K1_WAVES
 #define K1_WAVES 2
 #endif
+#ifndef PCS_LITE_LDS_ROW
+#define PCS_LITE_LDS_ROW 1
+#endif
+#ifndef K1_WAVES_LITE
+#define K1_WAVES_LITE 4  // pressure-only instantiation: 122 VGPR, 4 waves per SIMD (without -fno-slp-vectorize: 168 VGPR, 3 waves)
+#endif
 constexpr int K1_BINS = 4;
 
 // Bucket key of a staged row: model class (which branches of the Helmholtz energy the row needs) in
@@ -82,7 +88,7 @@ __device__ __forceinline__ int k1_bucket(const double* row) {
 // LITE (pressure-only output, fp32 pre-solve available): vle_fast_lite; rows without a usable fp32 result are
 // appended with bit 31 set (k_pure_vle_fallback takes them), rows for the robust pass without.
 template <bool LITE>
-__global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __restrict__ params,
+__global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure_vle(const double* __restrict__ params,
                                                     const double* __restrict__ temp, int64_t n,
                                                     double* __restrict__ p_sat, double* __restrict__ rho_eq,
                                                     double* __restrict__ rho_vl, uint8_t* __restrict__ status,
@@ -138,7 +144,11 @@ __global__ __launch_bounds__(BLOCK, K1_WAVES) void k_pure_vle(const double* __re
     VleResult res;
     int st;  // wave-uniform calls
 #if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
+#if PCS_LITE_LDS_ROW
+    if (LITE) st = vle_fast_lite(&lds[r * ROW_PAD], lds[r * ROW_PAD + 8], res);  // the row is re-read from LDS for the fp64 coefficients
+#else
     if (LITE) st = vle_fast_lite(par, T, res);
+#endif
     else st = rho_eq ? vle_fast<true>(par, T, res, 1e-8, TOL_STEP) : vle_fast<true>(par, T, res);
 #else
     st = rho_eq ? vle_fast<false>(par, T, res, 1e-8, TOL_STEP) : vle_fast<false>(par, T, res);

@@ -239,6 +239,9 @@ PCS_DEV R pure_a(const PureCoef<P>& c, const R& rho) {
 #ifndef PCS_D1S_CLOSED
 #define PCS_D1S_CLOSED 1
 #endif
+#ifndef PCS_ASSOC_CLOSED64
+#define PCS_ASSOC_CLOSED64 1  // closed-form association term in the fp64 finish (value + first derivative)
+#endif
 #if PCS_D1S_CLOSED
 // The pressure-only fp64 finish (R = D1s: a and a') with hard sphere, chain and dispersion in closed form, as the fp32
 // pre-solve does (pure_f32.hpp): a = rho F(eta) + rho^2 G(eta),
@@ -273,6 +276,30 @@ PCS_DEV D1s pure_a<double, D1s>(const PureCoef<double>& c, const D1s& rho) {
             a = a + ((rho * rho) * c.qm) * ((J1 * J1) * d_recip(J1 - rho * J2));
         }
         if (c.assoc) {
+#if PCS_ASSOC_CLOSED64
+            // closed form, value and first derivative (see assoc_closed_f32, pure_f32.hpp): a_assoc = rho q(S),
+            // a' = q + rho q_S S',  q_S = -na nb XA XB (the energy is stationary in the site fractions), S = rho da h(eta)
+            const double u_ = d_recip(1.0 - eta), eu = eta * u_;
+            const double h = u_ * (1.0 + eu * (1.5 + 0.5 * eu));
+            const double h1 = (u_ * u_) * (2.5 + eu * (4.0 + 1.5 * eu));
+            const double S = r * c.da * h, S1 = c.da * (h + eta * h1);
+            const double sa = c.na * S, sb = c.nb * S, t = sb - sa, aux = 1.0 - t;
+            const double sq = d_sqrt(aux * aux + 4.0 * sb);
+            double xa, xb;
+            if (t > 0.5) {
+                xa = 2.0 * d_recip(sq + 1.0 + t);
+                xb = (sq - 1.0 + t) * d_recip(2.0 * sb);
+            } else if (t < -0.5) {
+                xa = (sq - 1.0 - t) * d_recip(2.0 * sa);
+                xb = 2.0 * d_recip(sq + 1.0 - t);
+            } else {
+                xa = 2.0 * d_recip(sq + 1.0 + t);
+                xb = 2.0 * d_recip(sq + 1.0 - t);
+            }
+            const double q = c.na * (d_log(xa) - 0.5 * xa + 0.5) + c.nb * (d_log(xb) - 0.5 * xb + 0.5);
+            const double q1 = -(c.na * c.nb) * (xa * xb);
+            a = a + D1s(r * q, (q + r * q1 * S1) * rho.d1);
+#else
             D1s eta_m1 = d_recip(1.0 - eta_d);
             D1s k = eta_d * eta_m1;
             D1s delta = ((1.0 + k * (1.5 + 0.5 * k)) * eta_m1) * c.da;
@@ -294,6 +321,7 @@ PCS_DEV D1s pure_a<double, D1s>(const PureCoef<double>& c, const D1s& rho) {
                 xb = 2.0 * d_recip(sq + 1.0 - t);
             }
             a = a + rhoa * site_term(xa) + rhob * site_term(xb);
+#endif
         }
     }
     return a;

@@ -275,14 +275,26 @@ PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double to
     float dpl32 = 1.0f, dpv32 = 1.0f;
     PureCoefF cf;
     pure_coef_f32(cf, par, T);
+#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 1  // timing experiments only (scripts/dev/stage_time.py): fp32 coefficients
+    out.p_star = (double)(cf.ceta + cf.kd2 + cf.ai[3] + cf.bi[5] + cf.j1[2] + cf.j2[1] + cf.da); out.rho_l = out.rho_v = 1.0; out.iters = 0;
+    return ST_OK;
+#endif
 #ifdef PCS_DIAG_ITERS
     int diag = 0;
     const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32, &diag);
 #else
     const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32);
 #endif
+#if defined(PCS_STAGE_CUT) && (PCS_STAGE_CUT == 2 || PCS_STAGE_CUT == 3)  // after the fp32 liquid root (2, cut inside the pre-solve) / the whole pre-solve (3)
+    out.p_star = rl + rv + (double)(dpl32 + dpv32); out.rho_l = rl; out.rho_v = rv; out.iters = 0;
+    return warm ? ST_OK : ST_FALLBACK;
+#endif
     PureCoef<double> c;
     pure_coef<double>(c, par, T, false);
+#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 4  // + fp64 coefficients
+    out.p_star = rl + rv + c.ceta + c.kd2 + c.ai[3] + c.bi[5] + c.j1[2] + c.j2[1] + c.da; out.rho_l = rl; out.rho_v = rv; out.iters = 0;
+    return warm ? ST_OK : ST_FALLBACK;
+#endif
     bool active = warm && is_finite_bits(rv) && (rv < 0.7 * rl) && (dpl32 > 0.0f) && (dpv32 > 0.0f);
     bool done = false;
     out.iters = 0;

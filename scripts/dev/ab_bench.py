@@ -16,7 +16,7 @@ for nm in names:
     L.pcs_pure_vle_retry.argtypes = [vp, vp, ctypes.c_int64] + [vp] * 7
     libs[nm] = L
 p = torch.empty(n, dtype=torch.float64, device="cuda"); st = torch.empty(n, dtype=torch.uint8, device="cuda")
-ws = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+ws = torch.empty(n + 64, dtype=torch.int32, device="cuda")
 stream = vp(torch.cuda.current_stream().cuda_stream)
 def run(L, retry=False):
     args = (vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, None, vp(st.data_ptr()), None, vp(ws.data_ptr()), stream)

@@ -8,7 +8,7 @@ Pd, Td = torch.from_numpy(P).cuda(), torch.from_numpy(T).cuda()
 vp = ctypes.c_void_p
 names = sys.argv[1:]
 p = torch.empty(n, dtype=torch.float64, device="cuda"); st = torch.empty(n, dtype=torch.uint8, device="cuda")
-ws = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+ws = torch.empty(n + 64, dtype=torch.int32, device="cuda")
 libs = {}
 for nm in names:
     L = ctypes.CDLL(os.path.abspath(f"scratch/ab/lib_{nm}.so")); L.pcs_pure_vle_fast.argtypes = [vp, vp, ctypes.c_int64] + [vp] * 7; libs[nm] = L

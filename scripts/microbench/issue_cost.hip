@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void k(long long* cyc, double* sink, int iters
         if (CLS == 15) { REP8(F8b("v_cndmask_b32");) }
         if (CLS == 16) { REP8(D8u("v_fract_f64");) }
         if (CLS == 17) { REP8(D8b("v_max_f64");) }
+        if (CLS == 21) { REP8(D8("v_pk_fma_f32");) }  // packed fp32: register pairs
+        if (CLS == 22) { REP8(D8b("v_pk_mul_f32");) }
         if (CLS == 18) {  // v_cvt_f32_f64: double sources, float destinations
             REP8(asm volatile("v_cvt_f32_f64 %0, %8\nv_cvt_f32_f64 %1, %9\nv_cvt_f32_f64 %2, %10\nv_cvt_f32_f64 %3, %11\nv_cvt_f32_f64 %4, %12\nv_cvt_f32_f64 %5, %13\nv_cvt_f32_f64 %6, %14\nv_cvt_f32_f64 %7, %15"
                               : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)
@@ -116,5 +118,6 @@ int main(int argc, char** argv) {
     run<12>("v_rcp_f64", w); run<13>("v_sqrt_f64", w); run<14>("v_rsq_f64", w);
     run<16>("v_fract_f64", w); run<17>("v_max_f64", w);
     run<18>("v_cvt_f32_f64", w); run<19>("v_cvt_f64_f32", w); run<20>("v_ldexp_f64", w);
+    run<21>("v_pk_fma_f32", w); run<22>("v_pk_mul_f32", w);
     return 0;
 }
