@@ -18,7 +18,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 # -fno-slp-vectorize: the SLP vectoriser pairs fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 and pays for it with
 # ~25 % v_mov (operand pairs must sit in adjacent registers) and 168 instead of 122 VGPRs on k_pure_vle<true> (3 instead of
 # 4 waves per SIMD): 1.184 -> 0.943 ms per 1e7 rows without it (scripts/dev/ab_bench.py, round 2).
-RELAXED = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros", "-fno-slp-vectorize", "-DPCS_FAST_RCP", "-DPCS_F32_PRESOLVE"]
+RELAXED = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros", "-fno-slp-vectorize", "-DPCS_FAST_RCP", "-DPCS_FAST_LOG", "-DPCS_F32_PRESOLVE"]
 RELAXED_SOURCES = {"pure_kernels.hip"}
 RESOURCES = os.path.join(HERE, "build", "resources.json")  # per-kernel register / stack report of the last build
 

@@ -54,6 +54,10 @@ PCS_DEV F2 operator*(F2 a, F2 b) {
     return f2(a.v * b.v, fmaf(a.d1, b.v, a.v * b.d1), fmaf(a.d2, b.v, fmaf(2.0f * a.d1, b.d1, a.v * b.d2)));
 }
 PCS_DEV F2 chainf(F2 a, float f0, float f1, float f2_) { return f2(f0, f1 * a.d1, fmaf(f2_, a.d1 * a.d1, f1 * a.d2)); }
+// raw v_log_f32 / v_exp_f32 (the library __logf / __expf wrap them in a denormal rescue: v_cmp + v_cndmask + v_ldexp,
+// ~5 VALU each).  Arguments here are normal fp32 numbers or the lane falls back to the fp64 path (non-finite result).
+PCS_DEV float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }
+PCS_DEV float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
 PCS_DEV F2 recipf(F2 a) {
     float r = __builtin_amdgcn_rcpf(a.v);
     float r2 = r * r;
@@ -61,7 +65,7 @@ PCS_DEV F2 recipf(F2 a) {
 }
 PCS_DEV F2 logf2(F2 a) {
     float r = __builtin_amdgcn_rcpf(a.v);
-    return chainf(a, __logf(a.v), r, -r * r);
+    return chainf(a, f_log(a.v), r, -r * r);
 }
 PCS_DEV F2 sqrtf2(F2 a) {
     float s = __builtin_amdgcn_sqrtf(a.v);
@@ -109,7 +113,7 @@ PCS_DEV void pure_coef_f32(PureCoefF& f, const double* par, double T64) {
     const float rT = __builtin_amdgcn_rcpf((float)T64);
     const float s3 = sigma * sigma * sigma;
     const float e = eps * rT;
-    const float d = sigma * (1.0f - 0.12f * __expf(-3.0f * e));
+    const float d = sigma * (1.0f - 0.12f * f_exp(-3.0f * e));
     f.m = m;
     f.mm1 = m - 1.0f;
     f.ceta = (float)FRAC_PI_6 * (m * (d * d * d));
@@ -147,7 +151,7 @@ PCS_DEV void pure_coef_f32(PureCoefF& f, const double* par, double T64) {
     f.na = (float)par[6];
     f.nb = (float)par[7];
     const bool sites = (f.na != 0.0f) || (f.nb != 0.0f);
-    f.da = (__expf((float)par[5] * rT) - 1.0f) * s3 * (float)par[4];
+    f.da = (f_exp((float)par[5] * rT) - 1.0f) * s3 * (float)par[4];
     f.assoc = sites && f.da != 0.0f;
 }
 
@@ -182,7 +186,7 @@ PCS_DEV F2 core_closed_f32(const PureCoefF& c, float rho) {
     const float u = __builtin_amdgcn_rcpf(1.0f - eta), w = __builtin_amdgcn_rcpf(2.0f - eta);
     const float u2 = u * u, u3 = u2 * u, u4 = u2 * u2, w2 = w * w;
     const float HS = eta * (4.0f - 3.0f * eta) * u2, HS1 = (4.0f - 2.0f * eta) * u3, HS2 = (10.0f - 4.0f * eta) * u4;
-    const float LG = __logf((1.0f - 0.5f * eta) * u3), LG1 = 3.0f * u - w, LG2 = 3.0f * u2 - w2;
+    const float LG = f_log((1.0f - 0.5f * eta) * u3), LG1 = 3.0f * u - w, LG2 = 3.0f * u2 - w2;
     const float F = c.m * HS - c.mm1 * LG, F1 = c.m * HS1 - c.mm1 * LG1, F2_ = c.m * HS2 - c.mm1 * LG2;
     float I1, I1a, I1b, I2, I2a, I2b;
     horner3f<7>(c.ai, eta, I1, I1a, I1b);
@@ -249,7 +253,7 @@ PCS_DEV F2 assoc_closed_f32(const PureCoefF& c, float rho) {
         xa = 2.0f * __builtin_amdgcn_rcpf(sq + 1.0f + t);
         xb = 2.0f * __builtin_amdgcn_rcpf(sq + 1.0f - t);
     }
-    const float q = c.na * (__logf(xa) - 0.5f * xa + 0.5f) + c.nb * (__logf(xb) - 0.5f * xb + 0.5f);
+    const float q = c.na * (f_log(xa) - 0.5f * xa + 0.5f) + c.nb * (f_log(xb) - 0.5f * xb + 0.5f);
     const float nn = c.na * c.nb;
     const float q1 = -nn * xa * xb;
     const float al = c.nb * xa * xa, be = c.na * xb * xb;
@@ -417,7 +421,7 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
     rl_out = (double)rl; rv_out = ok ? 1.0 : 2.0; dpl_out = dpv_out = 1.0f; return ok;
 #endif
     EvalF l = pure_eval_f32(f, rl);
-    float rv = rl * __expf(l.mu);
+    float rv = rl * f_exp(l.mu);
 #if PCS_F32_VIRIAL
     {
         // second-virial correction of the ideal-gas estimate: ln rho + 2 B rho = ln rho_L + mu_L^res with
@@ -425,12 +429,12 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
         float B = (4.0f * f.m - 2.5f * f.mm1) * f.ceta + f.kd1 * f.ai[0] + f.kd2 * f.bi[0];
         if (f.polar) B += f.qm * f.j1[0];
         if (f.assoc) B -= f.na * f.nb * f.da;
-        const float Lg = __logf(rv);
+        const float Lg = f_log(rv);
         float r = rv;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             float den = fmaxf(1.0f + 2.0f * B * r, 0.3f);
-            float fr = __logf(r) + 2.0f * B * r - Lg;
+            float fr = f_log(r) + 2.0f * B * r - Lg;
             r = r * fmaxf(1.0f - fr * __builtin_amdgcn_rcpf(den), 0.2f);
         }
         if (finitef(r) && r > 0.0f) rv = r;
@@ -450,12 +454,12 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
             dpv_last = v.dp;
             n_cpl++;
             float iv = __builtin_amdgcn_rcpf(rv), il = __builtin_amdgcn_rcpf(rl);
-            float ps = -(v.a * iv - l.a * il + __logf(rv * il)) * __builtin_amdgcn_rcpf(iv - il);
+            float ps = -(v.a * iv - l.a * il + f_log(rv * il)) * __builtin_amdgcn_rcpf(iv - il);
             float dl = -(l.p - ps) * __builtin_amdgcn_rcpf(l.dp);
             float dv = -(v.p - ps) * __builtin_amdgcn_rcpf(v.dp);
             float rln = rl + dl, rvn = rv + dv;
             // a large downward vapour step (poor first estimate at very low pressures) is taken in ln(rho) instead
-            if (rvn < 0.3f * rv) rvn = rv * __expf(dv * iv);
+            if (rvn < 0.3f * rv) rvn = rv * f_exp(dv * iv);
             if (!finitef(rln) || !finitef(rvn) || !(v.dp > 0.0f) || !(l.dp > 0.0f) || !(rvn > 1e-30f) || !(rvn < 0.6f * rln)) {
                 if (diag) code = (!finitef(rln) || !finitef(rvn)) ? 10 : !(v.dp > 0.0f) ? 11 : !(l.dp > 0.0f) ? 12 : !(rvn > 1e-30f) ? 13 : 14;
                 ok = false;

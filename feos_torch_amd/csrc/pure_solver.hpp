@@ -157,11 +157,13 @@ struct VleStep {
 };
 PCS_DEV VleStep vle_step(const Eval& l, const Eval& v, double rl, double rv) {
     VleStep s;
-    double inv_v = 1.0 / rv, inv_l = 1.0 / rl;
-    double inv_dv = 1.0 / (inv_v - inv_l);
-    s.p_star = -(v.a * inv_v - l.a * inv_l + log(rv * inv_l)) * inv_dv;
+    // d_recip / d_log: the refined hardware reciprocal and the short logarithm where the unit is built with
+    // PCS_FAST_RCP / PCS_FAST_LOG (dual.hpp), the IEEE division and library log otherwise
+    double inv_v = d_recip(rv), inv_l = d_recip(rl);
+    double inv_dv = d_recip(inv_v - inv_l);
+    s.p_star = -(v.a * inv_v - l.a * inv_l + d_log(rv * inv_l)) * inv_dv;
     double rl_res = l.p - s.p_star, rv_res = v.p - s.p_star;
-    double il = 1.0 / l.dp, iv = 1.0 / v.dp;
+    double il = d_recip(l.dp), iv = d_recip(v.dp);
     s.dl = -rl_res * il;
     s.dv = -rv_res * iv;
     s.p_corr = s.p_star + 0.5 * ((rv_res * rv_res) * (inv_v * inv_v) * iv - (rl_res * rl_res) * (inv_l * inv_l) * il) * inv_dv;

@@ -11,7 +11,7 @@ L = ctypes.CDLL(os.path.abspath("scratch/ab/lib_diag.so"))
 L.pcs_pure_vle_fast.argtypes = [vp, vp, ctypes.c_int64] + [vp] * 7
 p = torch.empty(n, dtype=torch.float64, device="cuda"); st = torch.empty(n, dtype=torch.uint8, device="cuda")
 it = torch.zeros(n, dtype=torch.int32, device="cuda")
-ws = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+ws = torch.empty(n + 64, dtype=torch.int32, device="cuda")
 L.pcs_pure_vle_fast(vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, None, vp(st.data_ptr()), vp(it.data_ptr()), vp(ws.data_ptr()), vp(torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
 it = it.cpu().numpy()
