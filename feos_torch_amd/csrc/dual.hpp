@@ -45,7 +45,13 @@ PCS_DEV double d_log(double x) {
     R = __builtin_fma(R, z, 2.857142874366239149e-01);
     R = __builtin_fma(R, z, 3.999999999940941908e-01);
     R = __builtin_fma(R, z, 6.666666666666735130e-01);
-    return __builtin_fma((double)e, 0.69314718055994530942, __builtin_fma(s, R * z, s + s));
+    double r = __builtin_fma((double)e, 0.69314718055994530942, __builtin_fma(s, R * z, s + s));
+#if PCS_FAST_LOG == 2
+    // the mixture / gc solvers detect degenerate states by the IEEE results of the library log: keep them
+    // (positive normal and subnormal arguments take the short form; frexp is exact on subnormals)
+    if (!__builtin_amdgcn_class(x, 0x180)) r = (x == 0.0) ? -__builtin_inf() : (x > 0.0 ? x : __builtin_nan(""));
+#endif
+    return r;
 }
 #else
 PCS_DEV double d_log(double x) { return log(x); }
@@ -61,8 +67,16 @@ PCS_DEV double d_cbrt(double x) { return cbrt(x); }
 #ifdef PCS_FAST_RCP
 PCS_DEV double d_recip(double x) {
     double r = __builtin_amdgcn_rcp(x);
+#if PCS_FAST_RCP == 2
+    // mixture / gc units: the refinement only where the estimate is an ordinary number, so that 1/0 = inf, 1/inf = 0 and
+    // NaN propagate as with the IEEE division (the solvers walk through degenerate pure-component limits on them)
+    const double r0 = r;
+#endif
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#if PCS_FAST_RCP == 2
+    if (!__builtin_amdgcn_class(r0, 0x108)) r = r0;  // not a +-normal number: keep the hardware result
+#endif
     return r;
 }
 #else

@@ -288,6 +288,22 @@ __global__ __launch_bounds__(256) void k_mix_class_scatter(const double* __restr
     if (i < n) perm[base[bin] + rank] = (int32_t)i;
 }
 
+// PCS_QUEUE_LDS_COEF = 1: the work-queue kernel keeps each lane's model coefficients in LDS (520 B per lane, 32.5 KB per
+// wave, one wave per SIMD: 130 of the CU's 160 KB).  The evaluation is a non-inlined call (it needs the whole VGPR file), so the coefficients
+// cannot stay in registers across it; handed over by reference they live in private memory and the callee reads them back
+// with ~37 flat loads per call (a memory round trip the single resident wave cannot hide: 24 % of the wave's cycles were
+// SQ_WAIT_ANY).  With the model object in LDS the same flat loads resolve in the LDS aperture.
+// Measured (round 2, 1e6 rows): SQ_WAIT_ANY 8.7e8 -> 6.1e8 quad-cycles per dew launch, but the build then saves the
+// callee-saved VGPRs of the evaluation function through scratch (79 stores + 79 loads per call) and the kernel time does
+// not move (2.92 / 6.64 ms against 2.90 / 6.70 ms): off.
+#ifndef PCS_QUEUE_LDS_COEF
+#define PCS_QUEUE_LDS_COEF 0
+#endif
+struct alignas(16) MixModelSlot {
+    MixModel m;
+    double pad[(520 - sizeof(MixModel) % 520) / 8];  // lane stride 520 B = 130 dwords: consecutive lanes two banks apart
+};
+
 template <bool DEW>
 __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew_queue(const double* __restrict__ params,
                                                              const double* __restrict__ kij,
@@ -297,6 +313,9 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
                                                              const int32_t* __restrict__ perm, int32_t* __restrict__ ctrl,
                                                              double* __restrict__ p_out, double* __restrict__ rho4,
                                                              uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
+#if PCS_QUEUE_LDS_COEF
+    __shared__ MixModelSlot slots[64];
+#endif
     const int lane = threadIdx.x;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int total = (int)n;
@@ -304,7 +323,11 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
     bool drained = false;   // queue head passed n (wave-uniform)
     BdLane<DEW> L;
     L.idle();
+#if PCS_QUEUE_LDS_COEF
+    MixModel& m = slots[threadIdx.x].m;
+#else
     MixModel m;
+#endif
     int64_t row = -1;
     double T = 0.0;
     int evals = 0;  // evaluations of this lane's current row (bounded by BD_EVAL_GUARD: the loop below cannot hang)
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
 }
 
 // PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420): a, p, mu_i, v_i at given partial densities
-__global__ __launch_bounds__(MBLOCK) void k_mix_derivatives(const double* __restrict__ params,
+__global__ __launch_bounds__(MBLOCK, 2) void k_mix_derivatives(const double* __restrict__ params,
                                                             const double* __restrict__ kij,
                                                             const double* __restrict__ temp,
                                                             const double* __restrict__ rho, int64_t n,

@@ -28,8 +28,8 @@ namespace pcs {
 struct PhaseEval {
     double r0, r1;
     double a, g0, g1, h00, h01, h11;
-    PCS_DEV double mu0() const { return log(r0) + g0; }
-    PCS_DEV double mu1() const { return log(r1) + g1; }
+    PCS_DEV double mu0() const { return d_log(r0) + g0; }
+    PCS_DEV double mu1() const { return d_log(r1) + g1; }
     PCS_DEV double p() const { return r0 + r1 - a + r0 * g0 + r1 * g1; }
     PCS_DEV double dp0() const { return 1.0 + r0 * h00 + r1 * h01; }  // dp/drho_0
     PCS_DEV double dp1() const { return 1.0 + r0 * h01 + r1 * h11; }
@@ -42,7 +42,7 @@ struct PhaseEval {
 #define PCS_EVAL_ATTR __device__ __attribute__((noinline))
 #endif
 template <class Model>
-PCS_EVAL_ATTR PhaseEval phase_eval(const Model& m, double r0, double r1) {
+PCS_DEV PhaseEval phase_eval_inline(const Model& m, double r0, double r1) {
     typedef T2<double> R;
     R a = m.template a<R>(R(r0, 1.0, 0.0, 0.0, 0.0, 0.0), R(r1, 0.0, 1.0, 0.0, 0.0, 0.0));
     PhaseEval e;
@@ -50,6 +50,8 @@ PCS_EVAL_ATTR PhaseEval phase_eval(const Model& m, double r0, double r1) {
     e.a = a.v; e.g0 = a.g0; e.g1 = a.g1; e.h00 = a.h00; e.h01 = a.h01; e.h11 = a.h11;
     return e;
 }
+template <class Model>
+PCS_EVAL_ATTR PhaseEval phase_eval(const Model& m, double r0, double r1) { return phase_eval_inline(m, r0, r1); }
 
 // p and dp/drho along a fixed composition (x0, x1): one D2 evaluation
 template <class Model>
@@ -166,7 +168,7 @@ PCS_DEV double bubble_dew_formula(const PhaseEval& s, const PhaseEval& n) {
     double d0 = s.dp0(), d1 = s.dp1();
     double den = 1.0 / (s.r0 * d0 + s.r1 * d1);
     double v = (y0 * d0 + y1 * d1) * den;
-    double g = y0 * (log(n.r0 / s.r0) - s.g0) + y1 * (log(n.r1 / s.r1) - s.g1);
+    double g = y0 * (d_log(n.r0 / s.r0) - s.g0) + y1 * (d_log(n.r1 / s.r1) - s.g1);
     return -(n.a / rho_i + s.p() * v + g - 1.0) / (1.0 / rho_i - v);
 }
 
@@ -249,8 +251,8 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
             // The sweep is a scalar fixed-point map xi -> G(xi) in xi = ln(x_1/x_2); its plain iteration converges
             // linearly (slowly for strongly non-ideal liquids), so from the second sweep on the secant step on
             // r(xi) = G(xi) - xi is taken when it is well defined (r decreasing, step at most ln 5).
-            double xi = log(x0 / x1);
-            double res = log(n0 / n1) - xi;
+            double xi = d_log(x0 / x1);
+            double res = d_log(n0 / n1) - xi;
             bool secant = false;
             // Bracket of the fixed point: r > 0 at xi_lo, r < 0 at xi_hi (r decreases through a stable fixed point).  For
             // strongly non-ideal liquids the map cycles around a steep or discontinuous stretch of r (the liquid root
@@ -280,7 +282,7 @@ PCS_DEV int bubble_dew_solve(const Model& m, double z0, double p_init, MixResult
             }
             bool narrow = false;
             if (xi_lo < xi_hi && xi_lo > -1e299 && xi_hi < 1e299) {
-                double xin = log(x0 / x1);
+                double xin = d_log(x0 / x1);
                 if (!(xin > xi_lo && xin < xi_hi)) {
                     double e = exp(0.5 * (xi_lo + xi_hi));
                     x0 = e / (1.0 + e);

@@ -267,8 +267,8 @@ struct BdLane {
             const double sum = (w0 + w1) / (rlc * exp(Gm));
             double n0 = w0 / (w0 + w1), n1 = w1 / (w0 + w1);
             const double dx = fabs(n0 - x0);
-            const double xi = log(x0 / x1);
-            const double res = log(n0 / n1) - xi;
+            const double xi = d_log(x0 / x1);
+            const double res = d_log(n0 / n1) - xi;
             bool secant = false;
             // bracket of the fixed point: r > 0 at xi_lo, r < 0 at xi_hi (see mix_solver.hpp)
             if (res > 0.0 && xi > xi_lo) xi_lo = xi;
@@ -294,7 +294,7 @@ struct BdLane {
             }
             bool narrow = false;
             if (xi_lo < xi_hi && xi_lo > -1e299 && xi_hi < 1e299) {
-                const double xin = log(x0 / x1);
+                const double xin = d_log(x0 / x1);
                 if (!(xin > xi_lo && xin < xi_hi)) {
                     const double ee = exp(0.5 * (xi_lo + xi_hi));
                     x0 = ee / (1.0 + ee);
