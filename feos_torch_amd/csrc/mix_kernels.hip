@@ -10,6 +10,7 @@
 #include "../../include/pcsaft_hip.h"
 #include "abi_common.hpp"
 #include "mix_model.hpp"
+#include <cstddef>
 #include "mix_solver.hpp"
 #include "mix_solver_sm.hpp"
 #ifndef PCS_MIX_SM
@@ -32,6 +33,13 @@ namespace {
 #endif
 constexpr int MBLOCK = PCS_MBLOCK;
 
+// PCS_MIX_PRELOAD = 1 (experiment, off): all coefficient loads of the evaluation function issued up front.  The ten
+// s_waitcnt of the function become one; SQ_WAIT_ANY drops 8.6e8 -> 6.9e8 quad-cycles per dew launch and SQ_WAIT_INST_ANY
+// rises by as much -- the kernel time does not move (2.84 / 6.44 ms vs 2.81 / 6.43 ms).  The single resident wave is
+// stalled by instruction dependencies, not by these loads.
+#ifndef PCS_MIX_PRELOAD
+#define PCS_MIX_PRELOAD 0
+#endif
 struct MixModel {
     MixCoef<double> c;
 #if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2  // diagnostics builds: evaluation counters
@@ -41,7 +49,30 @@ struct MixModel {
         return mix_a<double, R>(c, r0, r1);
     }
 #else
-    template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return mix_a<double, R>(c, r0, r1); }
+    template <class R> PCS_DEV R a(const R& r0, const R& r1) const {
+#if PCS_MIX_PRELOAD
+        // The solvers' evaluation function receives the model by reference (private memory).  Left to the compiler its
+        // ~37 loads sit in ten groups next to their uses, each followed by s_waitcnt: ten exposed memory round trips per
+        // call with one wave per SIMD (SQ_WAIT_ANY = 23 % of the wave cycles).  Here every coefficient the row needs is
+        // read up front -- the empty asm statements keep the loads above them and their results in registers -- so one
+        // round trip is exposed instead.  (Volatile loads do not do it: the backend waits after each of them.)
+        if (sizeof(R) == sizeof(T2<double>)) {
+            MixCoef<double> l;
+            const double* src = reinterpret_cast<const double*>(&c);
+            double* dst = reinterpret_cast<double*>(&l);
+            constexpr int N = sizeof(MixCoef<double>) / 8;
+            static_assert(offsetof(MixCoef<double>, polar) % 8 == 0 && offsetof(MixCoef<double>, acls) % 8 == 0, "flag slots");
+            // (pj, tj of a non-polar row hold whatever mix_coef left there: loaded all the same, never used)
+#pragma unroll
+            for (int k = 0; k < N; k++) dst[k] = src[k];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < N; k++) asm volatile("" : "+v"(dst[k]));
+            return mix_a<double, R>(l, r0, r1);
+        }
+#endif
+        return mix_a<double, R>(c, r0, r1);
+    }
 #endif
     PCS_DEV double packing(double x0, double x1) const { return x0 * c.zk[3][0] + x1 * c.zk[3][1]; }
 };

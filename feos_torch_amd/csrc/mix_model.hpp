@@ -253,6 +253,20 @@ struct Packing {
     R zeta2, zeta3, z3m1, z3m2, omz;
 };
 
+// PCS_CONST_MEM: the 42 universal dispersion constants from constant memory (s_load_dwordx8/x16, a few scalar loads per
+// evaluation) instead of instruction literals (two s_mov_b32 per constant per use: 18 SALU per 100 VALU instructions in the
+// evaluation function, and with one wave per SIMD every scalar instruction costs an issue slot of that wave).
+#ifndef PCS_CONST_MEM
+#define PCS_CONST_MEM 0
+#endif
+#if PCS_CONST_MEM
+#define PCS_ROW7(X) {X[0], X[1], X[2], X[3], X[4], X[5], X[6]}
+alignas(64) static __constant__ double DISP_CM[6][7] = {PCS_ROW7(A0), PCS_ROW7(A1), PCS_ROW7(A2), PCS_ROW7(B0), PCS_ROW7(B1), PCS_ROW7(B2)};
+#define PCS_K(i, X) (disp_k + 7 * (i))
+#else
+#define PCS_K(i, X) X
+#endif
+
 // hard sphere (:56-60) + dispersion (:69-106) + dipoles (:156-208) for any coefficient struct C that
 // provides m[2], zk[4][2], A[3], B[3], polar, pj, tj (MixCoef, GcCoef).  Fills `pk`.
 template <class C, class R>
@@ -278,8 +292,12 @@ PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
     R rmb = d_recip(mbar);
     R m1 = (mbar - 1.0) * rmb;
     R m2 = m1 * ((mbar - 2.0) * rmb);
-    R I1 = horner_zeta<7>(A0, zeta3) + m1 * horner_zeta<7>(A1, zeta3) + m2 * horner_zeta<7>(A2, zeta3);
-    R I2 = horner_zeta<7>(B0, zeta3) + m1 * horner_zeta<7>(B1, zeta3) + m2 * horner_zeta<7>(B2, zeta3);
+#if PCS_CONST_MEM
+    const double* disp_k = &DISP_CM[0][0];
+    asm volatile("" : "+s"(disp_k));  // opaque: the initialiser is not folded back into literals
+#endif
+    R I1 = horner_zeta<7>(PCS_K(0, A0), zeta3) + m1 * horner_zeta<7>(PCS_K(1, A1), zeta3) + m2 * horner_zeta<7>(PCS_K(2, A2), zeta3);
+    R I2 = horner_zeta<7>(PCS_K(3, B0), zeta3) + m1 * horner_zeta<7>(PCS_K(4, B1), zeta3) + m2 * horner_zeta<7>(PCS_K(5, B2), zeta3);
     R z3m4 = z3m2 * z3m2;
     R t2 = z3m1 * d_recip(2.0 - zeta3);
     R poly = zeta3 * (20.0 + zeta3 * (-27.0 + zeta3 * (12.0 - 2.0 * zeta3)));

@@ -11,3 +11,8 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         acc[c].append(v)
 for c, v in sorted(acc.items()):
     print(f"{c:28s} n {len(v)} mean {sum(v)/len(v):.6g}")
+# kernel durations from the trace of the same run
+import re
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    d = [ (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if pat in r["Kernel_Name"]]
+    if d: print(f"{'duration_ms':28s} n {len(d)} mean {sum(d)/len(d):.4f}")
