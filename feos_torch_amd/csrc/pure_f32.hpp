@@ -37,6 +37,9 @@ namespace pcs {
 #ifndef PCS_F32_DENSE_RESTART
 #define PCS_F32_DENSE_RESTART 1
 #endif
+#ifndef PCS_F32_DENSE_LEVELS
+#define PCS_F32_DENSE_LEVELS 3  // restarts of the fp32 liquid root on the dense side (1 = eta 0.58 only)
+#endif
 #ifndef PCS_F32_LIQ_TOL
 #define PCS_F32_LIQ_TOL 1e-1f  // relative (scaled-Newton) step at which the fp32 liquid initialiser hands over to the coupled iteration
 #endif
@@ -377,15 +380,18 @@ PCS_DEV bool liquid_root_f32(const PureCoefF& f, float p_spec, float tol, float 
     bool ok = finitef(f.da) && finitef(f.kd2) && finitef(f.ceta) && f.ceta > 0.0f && finitef(p_spec);
     rl = 0.5f / f.ceta;
     bool done = !ok, dense = false;
+    int first = 0;  // iteration at which the current start density is evaluated
     for (int it = 0; it < cap; it++) {
         if (!done) {
             EvalF e = pure_eval_f32(f, rl);
             n_eval++;
             float res = e.p - p_spec;
-            if (PCS_F32_DENSE_RESTART && it == 0 && finitef(e.p) && !(res > 0.0f)) {
+            if (PCS_F32_DENSE_RESTART && it == first && it < PCS_F32_DENSE_LEVELS && finitef(e.p) && !(res > 0.0f)) {
+                // still on the dilute side of the root: next start 0.08 further up (eta = 0.58, 0.66, 0.74)
                 dense = true;
-                rl = 0.58f / f.ceta;
-            } else if (!finitef(e.p) || !(e.dp > 0.0f) || (it == (dense ? 1 : 0) && !(res > 0.0f))) {
+                first = it + 1;
+                rl = (0.58f + 0.08f * (float)it) / f.ceta;
+            } else if (!finitef(e.p) || !(e.dp > 0.0f) || (it == first && !(res > 0.0f))) {
                 ok = false;
                 done = true;
             } else {
@@ -406,22 +412,35 @@ PCS_DEV bool liquid_root_f32(const PureCoefF& f, float p_spec, float tol, float 
     return ok && done;
 }
 
-// fp32 pass.  Returns true with (rl, rv) close to the solution (typically 1e-6 relative) when
-// every step of the pass behaved; false = this lane must use the fp64 initialiser.
-// dpl_out / dpv_out: dp/drho of the two phases from the pass's last evaluations (one small step before the
-// returned densities): the second derivative the fp64 finish uses for its Newton steps.
-PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out, float& dpl_out, float& dpv_out,
-                              int* diag = nullptr) {
-    int n_liq = 0, n_cpl = 0, code = 0;
+// fp32 pass, in two resumable parts so that a kernel can hand the few lanes that need more coupled iterations than their
+// wave-mates to another wave (k_pure_vle<true>: block-level straggler exchange):
+//   presolve_begin:   zero-pressure liquid root, liquid state at it, virial-corrected ideal-gas vapour estimate
+//   presolve_coupled: coupled Newton towards the equal-area pressure from iteration s.it up to (excluding) it_end, or
+//                     until every lane of the wave is done
+// vle_presolve_f32 = begin + coupled(8).  s.ok: every step behaved (otherwise the lane uses the fp64 initialiser);
+// s.done && s.ok: converged to the fp32 noise floor (typically 1e-6 relative).  Not converged within the cap is fine: the
+// fp64 iteration continues from there.  l.dp / dpv: dp/drho of the two phases from the last evaluations (one small step
+// before the returned densities): the second derivative the fp64 finish uses for its Newton steps.
+struct PreState {
+    float rl, rv;
+    EvalF l;              // liquid state at rl (re-evaluated or carried by the Taylor expansion)
+    float dpv;            // dp/drho of the vapour at its last evaluation
+    float sl_prev, sv_prev;
+    int it, n_liq, code;  // coupled iterations done; diagnostics
+    bool ok, done;
+};
+
+PCS_DEV void presolve_begin(const PureCoefF& f, PreState& s) {
+    s.n_liq = 0; s.it = 0; s.code = 0;
+    s.dpv = 1.0f; s.sl_prev = 1.0f; s.sv_prev = 1.0f;
     // zero-pressure liquid, handed over to the coupled iteration at a loose step
-    float rl;
-    bool ok = liquid_root_f32(f, 0.0f, PCS_F32_LIQ_TOL, 1e-2f, 12, rl, n_liq);
-    bool done = ok;
+    bool ok = liquid_root_f32(f, 0.0f, PCS_F32_LIQ_TOL, 1e-2f, 12, s.rl, s.n_liq);
+    const float rl = s.rl;
 #if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 2  // timing experiments only
-    rl_out = (double)rl; rv_out = ok ? 1.0 : 2.0; dpl_out = dpv_out = 1.0f; return ok;
+    s.rv = ok ? 1.0f : 2.0f; s.l.a = s.l.p = s.l.mu = 0.0f; s.l.dp = 1.0f; s.ok = ok; s.done = true; return;
 #endif
-    EvalF l = pure_eval_f32(f, rl);
-    float rv = rl * f_exp(l.mu);
+    s.l = pure_eval_f32(f, rl);
+    float rv = rl * f_exp(s.l.mu);
 #if PCS_F32_VIRIAL
     {
         // second-virial correction of the ideal-gas estimate: ln rho + 2 B rho = ln rho_L + mu_L^res with
@@ -440,19 +459,27 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
         if (finitef(r) && r > 0.0f) rv = r;
     }
 #endif
-    if (diag) code = !ok ? 1 : !done ? 5 : !finitef(rv) ? 6 : !(l.dp > 0.0f) ? 7 : !(rv < 0.5f * rl) ? 8 : !(rv > 1e-30f) ? 9 : 0;
-    ok = ok && done && finitef(rv) && (l.dp > 0.0f) && (rv < 0.5f * rl) && (rv > 1e-30f);
-    // coupled Newton towards the equal-area pressure, to the fp32 noise floor
-    done = !ok;
-    float dpv_last = 1.0f, dl_taken = 0.0f;
-#if PCS_F32_PREDICT_STOP
-    float sl_prev = 1.0f, sv_prev = 1.0f;
-#endif
-    for (int it = 0; it < 8; it++) {
-        if (!done) {
+    s.code = !ok ? 1 : !finitef(rv) ? 6 : !(s.l.dp > 0.0f) ? 7 : !(rv < 0.5f * rl) ? 8 : !(rv > 1e-30f) ? 9 : 0;
+    ok = ok && finitef(rv) && (s.l.dp > 0.0f) && (rv < 0.5f * rl) && (rv > 1e-30f);
+    s.rv = rv;
+    s.ok = ok;
+    s.done = !ok;
+}
+
+PCS_DEV void presolve_coupled(const PureCoefF& f, PreState& s, int it_end) {
+    float rl = s.rl, rv = s.rv;
+    EvalF l = s.l;
+    bool ok = s.ok, done = s.done;
+    float dpv_last = s.dpv, dl_taken = 0.0f;
+    float sl_prev = s.sl_prev, sv_prev = s.sv_prev;
+    int n_cpl = s.it;
+    // lanes of one wave may resume at different iteration numbers (straggler exchange): `it` below only bounds the loop,
+    // the lane's own count n_cpl decides what the first-iteration rule of the stop criterion sees
+    for (int it = 0; it < it_end; it++) {
+        const bool act = !done && n_cpl < it_end;
+        if (act) {
             EvalF v = pure_eval_f32(f, rv);
             dpv_last = v.dp;
-            n_cpl++;
             float iv = __builtin_amdgcn_rcpf(rv), il = __builtin_amdgcn_rcpf(rl);
             float ps = -(v.a * iv - l.a * il + f_log(rv * il)) * __builtin_amdgcn_rcpf(iv - il);
             float dl = -(l.p - ps) * __builtin_amdgcn_rcpf(l.dp);
@@ -461,7 +488,7 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
             // a large downward vapour step (poor first estimate at very low pressures) is taken in ln(rho) instead
             if (rvn < 0.3f * rv) rvn = rv * f_exp(dv * iv);
             if (!finitef(rln) || !finitef(rvn) || !(v.dp > 0.0f) || !(l.dp > 0.0f) || !(rvn > 1e-30f) || !(rvn < 0.6f * rln)) {
-                if (diag) code = (!finitef(rln) || !finitef(rvn)) ? 10 : !(v.dp > 0.0f) ? 11 : !(l.dp > 0.0f) ? 12 : !(rvn > 1e-30f) ? 13 : 14;
+                s.code = (!finitef(rln) || !finitef(rvn)) ? 10 : !(v.dp > 0.0f) ? 11 : !(l.dp > 0.0f) ? 12 : !(rvn > 1e-30f) ? 13 : 14;
                 ok = false;
                 done = true;
             } else {
@@ -470,7 +497,7 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
                 float sl = fabsf(dl) * il, sv = fabsf(dv) * iv;
                 float pl = sl * sl * fminf(sl * __builtin_amdgcn_rcpf(sl_prev * sl_prev), PCS_F32_PREDICT_CMAX);
                 float pv = sv * sv * fminf(sv * __builtin_amdgcn_rcpf(sv_prev * sv_prev), PCS_F32_PREDICT_CMAX);
-                done = ((sl <= 2e-6f) && (sv <= 3e-5f)) || (it > 0 && sl < 1e-2f && sv < 1e-2f && pl <= PCS_F32_PREDICT_TOL_L && pv <= PCS_F32_PREDICT_TOL_V);
+                done = ((sl <= 2e-6f) && (sv <= 3e-5f)) || (n_cpl > 0 && sl < 1e-2f && sv < 1e-2f && pl <= PCS_F32_PREDICT_TOL_L && pv <= PCS_F32_PREDICT_TOL_V);
                 sl_prev = sl; sv_prev = sv;
 #else
                 done = (fabsf(dl) <= 2e-6f * rl) && (fabsf(dv) <= 3e-5f * rv);
@@ -479,8 +506,9 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
                 rl = rln;
                 rv = rvn;
             }
+            n_cpl++;
         }
-        if (__ballot(!done) == 0ull) break;
+        // the liquid state follows every taken step (also the last one of this call: a resumed lane starts from it)
 #if PCS_F32_LIQ_TAYLOR
         // the liquid barely moves after the first iteration: a lane whose liquid step was below 1e-3 carries its
         // liquid state to the new density by the Taylor expansion (a to 2nd, p to 1st order, dp kept) instead of a
@@ -488,8 +516,9 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
         // choice is per lane (a row's result does not depend on its wave-mates); the evaluation is skipped when no
         // lane of the wave needs it.
         {
-            const bool reeval = !done && !(fabsf(dl_taken) <= PCS_F32_TAYLOR_MAX * rl);
-            if (!done && !reeval) {
+            const bool moved = act && !done;
+            const bool reeval = moved && !(fabsf(dl_taken) <= PCS_F32_TAYLOR_MAX * rl);
+            if (moved && !reeval) {
                 const float a2 = (l.dp - 1.0f) * __builtin_amdgcn_rcpf(rl - dl_taken);  // a'' at the expansion point
                 l.a = fmaf(dl_taken, fmaf(0.5f * a2, dl_taken, l.mu), l.a);
                 l.mu = fmaf(a2, dl_taken, l.mu);
@@ -500,15 +529,25 @@ PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out
             }
         }
 #else
-        if (!done) l = pure_eval_f32(f, rl);
+        if (act && !done) l = pure_eval_f32(f, rl);
 #endif
+        if (__ballot(!done && n_cpl < it_end) == 0ull) break;
     }
-    rl_out = (double)rl;
-    rv_out = (double)rv;
-    dpl_out = l.dp;
-    dpv_out = dpv_last;
-    if (diag) *diag = n_liq | (n_cpl << 8) | (code << 16);  // diagnostics builds only
-    return ok;  // not converged within the caps is fine: the fp64 iteration continues from here
+    s.rl = rl; s.rv = rv; s.l = l; s.dpv = dpv_last; s.sl_prev = sl_prev; s.sv_prev = sv_prev;
+    s.it = n_cpl; s.ok = ok; s.done = done;
+}
+
+PCS_DEV bool vle_presolve_f32(const PureCoefF& f, double& rl_out, double& rv_out, float& dpl_out, float& dpv_out,
+                              int* diag = nullptr) {
+    PreState s;
+    presolve_begin(f, s);
+    presolve_coupled(f, s, 8);
+    rl_out = (double)s.rl;
+    rv_out = (double)s.rv;
+    dpl_out = s.l.dp;
+    dpv_out = s.dpv;
+    if (diag) *diag = s.n_liq | (s.it << 8) | (s.code << 16);  // diagnostics builds only
+    return s.ok;
 }
 
 }  // namespace pcs

@@ -31,7 +31,10 @@ thread_local char pcs_abi::g_err[256] = "";
 
 namespace {
 
-constexpr int BLOCK = 256;
+#ifndef PCS_BLOCK
+#define PCS_BLOCK 256
+#endif
+constexpr int BLOCK = PCS_BLOCK;
 constexpr int ROW_PAD = 9;  // doubles per staged row (8 + 1 pad): bank-conflict-free per-lane reads
 
 // Cooperative, coalesced load of the workgroup's parameter rows into LDS, then one row per lane.
@@ -70,6 +73,35 @@ __device__ __forceinline__ void stage_params(const double* __restrict__ params, 
 #define K1_WAVES_LITE 4  // pressure-only instantiation: 122 VGPR, 4 waves per SIMD (without -fno-slp-vectorize: 168 VGPR, 3 waves)
 #endif
 constexpr int K1_BINS = 4;
+// PCS_K1_EXCHANGE = 1 (experiment, off): block-level straggler exchange of the fp32 coupled iteration (see the LITE branch
+// of k_pure_vle).  Measured on 1e7 rows: 0.797 ms without, 0.815 ms with it at 256 threads per workgroup, 0.834 ms at 512
+// (0.824 ms at 512 without), 1.014 ms at 1024 -- the two barriers and the serial straggler wave cost more than the
+// 1.4 iterations per wave they save.
+#ifndef PCS_K1_EXCHANGE
+#define PCS_K1_EXCHANGE 0
+#endif
+#ifndef K1_MAIN_ITS
+#define K1_MAIN_ITS 2
+#endif
+#if PCS_K1_EXCHANGE && defined(PCS_F32_PRESOLVE)
+// state of a parked lane (fp32 pre-solve not converged after K1_MAIN_ITS coupled iterations) + its staged row
+struct ParkedLane {
+    float v[9];
+    int meta;  // row (10 bits) | iteration count (6) | n_liq (8) | ok (1) | done (1)
+    __device__ __forceinline__ void put(const PreState& s, int row) {
+        v[0] = s.rl; v[1] = s.rv; v[2] = s.l.a; v[3] = s.l.p; v[4] = s.l.dp; v[5] = s.l.mu; v[6] = s.dpv; v[7] = s.sl_prev; v[8] = s.sv_prev;
+        meta = row | (s.it << 10) | (s.n_liq << 16) | ((s.ok ? 1 : 0) << 24) | ((s.done ? 1 : 0) << 25);
+    }
+    __device__ __forceinline__ int get(PreState& s) const {
+        s.rl = v[0]; s.rv = v[1]; s.l.a = v[2]; s.l.p = v[3]; s.l.dp = v[4]; s.l.mu = v[5]; s.dpv = v[6]; s.sl_prev = v[7]; s.sv_prev = v[8];
+        s.it = (meta >> 10) & 63; s.n_liq = (meta >> 16) & 255; s.ok = (meta >> 24) & 1; s.done = (meta >> 25) & 1; s.code = 0;
+        return meta & 1023;
+    }
+};
+#else
+#undef PCS_K1_EXCHANGE
+#define PCS_K1_EXCHANGE 0
+#endif
 
 // Bucket key of a staged row: model class (which branches of the Helmholtz energy the row needs) in
 // Gray order none, polar, polar+assoc, assoc -- neighbouring buckets share a branch.  Lanes of one
@@ -96,6 +128,10 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
     __shared__ double lds[BLOCK * ROW_PAD];  // 8 parameters + T per row
     __shared__ int perm[BLOCK];
     __shared__ int bins[K1_BINS];
+#if PCS_K1_EXCHANGE
+    __shared__ ParkedLane parked[LITE ? BLOCK : 1];
+    __shared__ int n_parked;
+#endif
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
     // cooperative, coalesced staging (rows past n clamp to row n-1; never stored)
@@ -115,6 +151,9 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
         const int64_t g = row0 + t;
         lds[t * ROW_PAD + 8] = temp[g < n ? g : n - 1];
         if (t < K1_BINS) bins[t] = 0;
+#if PCS_K1_EXCHANGE
+        if (t == 0) n_parked = 0;
+#endif
     }
     __syncthreads();
     const int key = k1_bucket(&lds[t * ROW_PAD]);
@@ -144,7 +183,48 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
     VleResult res;
     int st;  // wave-uniform calls
 #if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
-#if PCS_LITE_LDS_ROW
+#if PCS_K1_EXCHANGE
+    if (LITE) {
+        // fp32 pre-solve with the block-level straggler exchange: every wave runs at most K1_MAIN_ITS coupled iterations
+        // (92 % of the lanes need exactly two); lanes that are not converged then park their state in LDS, and the
+        // parked lanes of the whole workgroup are finished together -- 64 at a time, by the first wave(s) -- instead of
+        // every wave iterating on for its few slow lanes (3.4 iterations per wave against 2.1 per lane).  A parked
+        // lane's iteration continues from its own state with coefficients recomputed from its staged row: its result
+        // does not depend on which lanes it shares a wave with.
+        const double* row = &lds[r * ROW_PAD];
+        PreState ps;
+        {
+            PureCoefF cf;
+            pure_coef_f32(cf, row, T);
+            presolve_begin(cf, ps);
+            presolve_coupled(cf, ps, K1_MAIN_ITS);
+        }
+        int slot = -1;
+        if (ps.ok && !ps.done) {
+            slot = atomicAdd(&n_parked, 1);
+            parked[slot].put(ps, r);
+        }
+        __syncthreads();
+        const int np = n_parked;
+        for (int k = t; k < ((np + 63) & ~63); k += BLOCK) {  // whole waves: the loops inside are wave-uniform
+            PreState q;
+            PureCoefF cf;
+            int rq = 0;
+            const bool have = k < np;
+            if (have) rq = parked[k].get(q);
+            else { q.ok = false; q.done = true; q.it = 0; q.rl = q.rv = 1.0f; q.l.a = q.l.p = q.l.mu = 0.0f; q.l.dp = 1.0f; q.dpv = 1.0f; q.sl_prev = q.sv_prev = 1.0f; q.n_liq = q.code = 0; }
+            pure_coef_f32(cf, &lds[rq * ROW_PAD], lds[rq * ROW_PAD + 8]);
+            presolve_coupled(cf, q, 8);
+            if (have) parked[k].put(q, rq);
+        }
+        __syncthreads();
+        if (slot >= 0) parked[slot].get(ps);
+        st = vle_lite_finish(row, T, ps.ok, (double)ps.rl, (double)ps.rv, ps.l.dp, ps.dpv, res);
+#ifdef PCS_DIAG_ITERS
+        res.iters |= (ps.n_liq | (ps.it << 8) | (ps.code << 16)) << 8;
+#endif
+    }
+#elif PCS_LITE_LDS_ROW
     if (LITE) st = vle_fast_lite(&lds[r * ROW_PAD], lds[r * ROW_PAD + 8], res);  // the row is re-read from LDS for the fp64 coefficients
 #else
     if (LITE) st = vle_fast_lite(par, T, res);

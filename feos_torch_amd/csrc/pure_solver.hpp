@@ -272,22 +272,11 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
 // steers the step (error ~1e-3 of a ~1e-6 step); the residuals and p* are fp64.  Lanes without a usable fp32
 // result return ST_FALLBACK (the all-fp64 path runs on them in a separate small kernel, which keeps this one at
 // 162 VGPRs), lanes that fail afterwards ST_RETRY (robust pass).
-PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
-    double rl = 0.0, rv = 0.0;
-    float dpl32 = 1.0f, dpv32 = 1.0f;
-    PureCoefF cf;
-    pure_coef_f32(cf, par, T);
-#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 1  // timing experiments only (scripts/dev/stage_time.py): fp32 coefficients
-    out.p_star = (double)(cf.ceta + cf.kd2 + cf.ai[3] + cf.bi[5] + cf.j1[2] + cf.j2[1] + cf.da); out.rho_l = out.rho_v = 1.0; out.iters = 0;
-    return ST_OK;
-#endif
-#ifdef PCS_DIAG_ITERS
-    int diag = 0;
-    const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32, &diag);
-#else
-    const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32);
-#endif
-#if defined(PCS_STAGE_CUT) && (PCS_STAGE_CUT == 2 || PCS_STAGE_CUT == 3)  // after the fp32 liquid root (2, cut inside the pre-solve) / the whole pre-solve (3)
+// vle_fast_lite = fp32 pre-solve (pure_f32.hpp) + vle_lite_finish; k_pure_vle<true> runs the two parts itself with the
+// block-level straggler exchange in between.
+PCS_DEV int vle_lite_finish(const double* par, double T, bool warm, double rl, double rv, float dpl32, float dpv32,
+                            VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
+#if defined(PCS_STAGE_CUT) && (PCS_STAGE_CUT == 2 || PCS_STAGE_CUT == 3)  // timing experiments (scripts/dev/stage_time.py): after the fp32 liquid root (2, cut inside the pre-solve) / the whole pre-solve (3)
     out.p_star = rl + rv + (double)(dpl32 + dpv32); out.rho_l = rl; out.rho_v = rv; out.iters = 0;
     return warm ? ST_OK : ST_FALLBACK;
 #endif
@@ -333,12 +322,30 @@ PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double to
         }
         if (__ballot(active && !done) == 0ull) break;
     }
-#ifdef PCS_DIAG_ITERS
-    out.iters |= diag << 8;
-#endif
     if (!warm || (active && !done)) return ST_FALLBACK;
     if (done && out.rho_v < 0.7 * out.rho_l && vapour_is_physical(out.p_star, out.rho_v)) return ST_OK;
     return ST_RETRY;
+}
+
+PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
+    double rl = 0.0, rv = 0.0;
+    float dpl32 = 1.0f, dpv32 = 1.0f;
+    PureCoefF cf;
+    pure_coef_f32(cf, par, T);
+#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 1  // timing experiments only: fp32 coefficients
+    out.p_star = (double)(cf.ceta + cf.kd2 + cf.ai[3] + cf.bi[5] + cf.j1[2] + cf.j2[1] + cf.da); out.rho_l = out.rho_v = 1.0; out.iters = 0;
+    return ST_OK;
+#endif
+#ifdef PCS_DIAG_ITERS
+    int diag = 0;
+    const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32, &diag);
+    const int st = vle_lite_finish(par, T, warm, rl, rv, dpl32, dpv32, out, tol_l, tol_v);
+    out.iters |= diag << 8;
+    return st;
+#else
+    const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32);
+    return vle_lite_finish(par, T, warm, rl, rv, dpl32, dpv32, out, tol_l, tol_v);
+#endif
 }
 #endif
 
