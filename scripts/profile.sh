@@ -15,7 +15,7 @@ export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra"
 PMCBENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra"
 hipcc -O3 --offload-arch=gfx950 -o /tmp/issue_cost $REPO/scripts/microbench/issue_cost.hip 2>/dev/null
-/tmp/issue_cost 3 > $OUT/issue_cost.jsonl
+/tmp/issue_cost 4 > $OUT/issue_cost.jsonl
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMCBENCH > $OUT/pmc_fetch.log 2>&1

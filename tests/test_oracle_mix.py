@@ -70,22 +70,34 @@ def test_bubble_dew_random_rows(oracle, gm, name, dew):
     # literal != safeguarded evaluation at the converged densities and excluded.
     P, K, T = np.array(g["params"]), np.array(g["kij"]), np.array(g["T"])
     valid = np.ones(len(T), dtype=bool)
+    noise = np.zeros(len(T))
     for cols in (slice(0, 2), slice(2, 4)):
-        lit = oracle.mix_derivatives(P, K, T, np.where(st[:, None], 1e-3, rho4[:, cols]), robust=False)
-        rob = oracle.mix_derivatives(P, K, T, np.where(st[:, None], 1e-3, rho4[:, cols]), robust=True)
+        rho = np.where(st[:, None], 1e-3, rho4[:, cols])
+        lit = oracle.mix_derivatives(P, K, T, rho, robust=False)
+        rob = oracle.mix_derivatives(P, K, T, rho, robust=True)
+        exact = oracle.mix_derivatives_exact(P, K, T, rho)
         valid &= np.abs(lit[2] - rob[2]).max(axis=1) < 1e-9
+        # the reference's fp64 formulas at these densities against the exact model: the cancellation of its
+        # self-association term (xb = 2/(sqrt + aux), feos_torch/pcsaft_mix.py:237-238), measured per row
+        noise = np.maximum(noise, np.abs(lit[2] - exact[2]).max(axis=1))
     assert valid[ok].mean() > 0.9
     keep = valid[ok]
-    # the golden values are the reference's fp64 tail at these densities.  Its self-association
-    # term cancels catastrophically for strongly associating rows (xb = 2/(sqrt + aux),
-    # feos_torch/pcsaft_mix.py:237-238), so the 80-bit evaluation differs by up to ~1e-8 there;
-    # the fp64 evaluation of the same literal formula reproduces the reference.
-    assert np.max(np.abs(p[ok] / want - 1)[keep]) < 1e-7
+    noise = noise[ok]
+    # The golden values are the reference's fp64 tail at these densities.  Per-row bound: 1e-10 where the reference's
+    # own evaluation is clean, 10 x its measured cancellation error on the (two) strongly associating rows
+    clean = noise < 1e-10
+    assert (keep & ~clean).sum() <= 3
+    tol = 1e-10 + 10.0 * noise
+    err = np.abs(p[ok] / want - 1)
+    assert np.all(err[keep] <= tol[keep]), (err[keep] / tol[keep]).max()
     p64, _, st64 = oracle.mix_bubble_dew(g["params"], g["kij"], g["T"], g["z"], g["p_init"], dew, prec=0)
     assert np.array_equal(st64, st)
-    assert np.max(np.abs(p64[ok] / want - 1)[keep]) < 1e-7  # rounding noise of the cancelling term itself
-    val, grad = oracle.mix_bubble_dew_grad(np.array(g["params"])[ok], np.array(g["kij"])[ok], np.array(g["T"])[ok], rho4[ok], dew)
+    err64 = np.abs(p64[ok] / want - 1)
+    assert np.all(err64[keep] <= tol[keep]), (err64[keep] / tol[keep]).max()
+    val, grad = oracle.mix_bubble_dew_grad(P[ok], K[ok], T[ok], rho4[ok], dew)
     wantg = np.concatenate([np.array(ref["grad_params"])[ok].reshape(-1, 16), np.array(ref["grad_kij"])[ok],
                             np.array(ref["grad_T"])[ok, None]], axis=1)
     scale = np.abs(wantg).max(axis=1, keepdims=True)
-    assert np.max((np.abs(grad - wantg) / scale)[keep]) < 1e-6
+    gerr = (np.abs(grad - wantg) / scale).max(axis=1)
+    gtol = 5e-10 + 30.0 * noise  # the gradient differentiates the cancelling term
+    assert np.all(gerr[keep] <= gtol[keep]), (gerr[keep] / gtol[keep]).max()
