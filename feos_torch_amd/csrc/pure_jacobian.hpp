@@ -16,13 +16,223 @@ constexpr int JAC_DIRS = 10;  // 8 parameters, T, p
 #ifndef PCS_JAC_CHUNK
 #define PCS_JAC_CHUNK 2
 #endif
+#ifndef PCS_JAC_ADJOINT
+#define PCS_JAC_ADJOINT 1  // closed-form coefficient adjoints + forward tangents of the coefficients only (0: tangents through everything)
+#endif
 constexpr int JAC_CHUNK = PCS_JAC_CHUNK;  // directions per pass
+
+// Adjoint of a(rho; c) with respect to the coefficient set at fixed density, in closed form (the expressions of the
+// D1s evaluation, pure_model.hpp):  g_k = da/dc_k.  Returns a.
+//   a = rho (m HS - mm1 LG) + rho^2 (kd1 I1 + kd2 C I2) + rho^2 qm J1^2/(J1 - rho J2) + rho q(S; na, nb),  S = rho da h(eta)
+//   d/dm = rho HS - rho^2 kd2 I2 C^2 A,  d/dmm1 = -rho LG + rho^2 kd2 I2 C^2 B   (C = 1/D, D = 1 + m A - mm1 B)
+//   d/dai[k] = rho^2 kd1 eta^k,  d/dbi[k] = rho^2 kd2 C eta^k,  d/dkd1 = rho^2 I1,  d/dkd2 = rho^2 C I2
+//   d/dj1[i] = rho^2 qm eta^i (2 J1/Dn - N/Dn^2),  d/dj2[i] = rho^3 qm eta^i N/Dn^2,  d/dqm = rho^2 N/Dn   (N = J1^2, Dn = J1 - rho J2)
+//   d/dna = rho ln XA,  d/dnb = rho ln XB,  d/dda = rho^2 h q_S,  q_S = -na nb XA XB   (the association energy is stationary in
+//   the site fractions: only the explicit dependences count)
+//   d/dceta = rho da/deta with every eta-dependence above.
+// R = double: the adjoints themselves; R = D1s seeded with d rho = 1: .d1 = adjoints of a' = da/drho (the pressure
+// p = rho - a + rho a' of the liquid-density Jacobians).
+template <class R>
+struct PureCoefAdj {
+    R m, mm1, ceta, ai[7], bi[7], kd1, kd2, j1[5], j2[4], qm, da, na, nb;
+};
+template <int N, class R>
+PCS_DEV void poly_and_derivative(const double* coef, const R& x, R& p, R& dp) {  // sum coef[k] x^k and its x-derivative
+    p = x * coef[N - 1] + coef[N - 2];
+    dp = x * ((N - 1) * coef[N - 1]) + (N - 2) * coef[N - 2];
+#pragma unroll
+    for (int k = N - 3; k >= 0; k--) {
+        p = p * x + coef[k];
+        if (k >= 1) dp = dp * x + k * coef[k];
+    }
+}
+template <class R>
+PCS_DEV R pure_a_adjoint(const PureCoef<double>& c, const R& r, PureCoefAdj<R>& g) {
+    const R eta = r * c.ceta, r2 = r * r;
+    const R u = d_recip(1.0 - eta), w2 = d_recip(2.0 - eta);
+    const R u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+    const R HS = (eta * (4.0 - 3.0 * eta)) * u2, HS1 = (4.0 - 2.0 * eta) * u3;
+    const R LG = d_log((1.0 - 0.5 * eta) * u3), LG1 = 3.0 * u - w2;
+    R I1, I1d, I2, I2d;
+    poly_and_derivative<7>(c.ai, eta, I1, I1d);
+    poly_and_derivative<7>(c.bi, eta, I2, I2d);
+    const R A = (eta * (8.0 - 2.0 * eta)) * u4, A1 = (8.0 + eta * (20.0 - 4.0 * eta)) * (u4 * u);
+    const R poly = eta * (20.0 + eta * (-27.0 + eta * (12.0 - 2.0 * eta)));
+    const R poly1 = 20.0 + eta * (-54.0 + eta * (36.0 - 8.0 * eta));
+    const R q = u2 * (w2 * w2);
+    const R B = poly * q, B1 = q * (poly1 + 2.0 * (poly * (u + w2)));
+    const R D = 1.0 + c.m * A - c.mm1 * B, D1_ = c.m * A1 - c.mm1 * B1;
+    const R C = d_recip(D), C1 = -(D1_ * (C * C));
+    R a = r * (c.m * HS - c.mm1 * LG) + r2 * (c.kd1 * I1 + c.kd2 * (C * I2));
+    R a_eta = r * (c.m * HS1 - c.mm1 * LG1) + r2 * (c.kd1 * I1d + c.kd2 * (C1 * I2 + C * I2d));
+    const R k2 = (r2 * c.kd2) * (I2 * (C * C));
+    g.m = r * HS - k2 * A;
+    g.mm1 = k2 * B - r * LG;
+    g.kd1 = r2 * I1;
+    g.kd2 = r2 * (C * I2);
+    {
+        R pa = r2 * c.kd1, pb = (r2 * c.kd2) * C;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            g.ai[k] = pa;
+            g.bi[k] = pb;
+            pa = pa * eta;
+            pb = pb * eta;
+        }
+    }
+    if (c.polar) {
+        R J1, J1d, J2, J2d;
+        poly_and_derivative<5>(c.j1, eta, J1, J1d);
+        poly_and_derivative<4>(c.j2, eta, J2, J2d);
+        const R Dn = J1 - r * J2, rD = d_recip(Dn), N = J1 * J1, NrD2 = N * (rD * rD);
+        a = a + (r2 * c.qm) * (N * rD);
+        g.qm = r2 * (N * rD);
+        R p1 = (r2 * c.qm) * (2.0 * (J1 * rD) - NrD2), p2 = (r2 * c.qm) * (r * NrD2);
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            g.j1[i] = p1;
+            if (i < 4) g.j2[i] = p2;
+            p1 = p1 * eta;
+            p2 = p2 * eta;
+        }
+        a_eta = a_eta + (r2 * c.qm) * (2.0 * ((J1 * J1d) * rD) - NrD2 * (J1d - r * J2d));
+    }
+    if (c.assoc) {
+        const R eu = eta * u;
+        const R h = u * (1.0 + eu * (1.5 + 0.5 * eu));
+        const R h1 = u2 * (2.5 + eu * (4.0 + 1.5 * eu));
+        const R S = (r * c.da) * h;
+        const R sa = c.na * S, sb = c.nb * S, t = sb - sa, aux = 1.0 - t;
+        const R sq = d_sqrt(aux * aux + 4.0 * sb);
+        R xa, xb;  // cancellation-free forms, see pure_a
+        const double tr = re(t);
+        if (tr > 0.5) {
+            xa = 2.0 * d_recip(sq + 1.0 + t);
+            xb = (sq - 1.0 + t) * d_recip(2.0 * sb);
+        } else if (tr < -0.5) {
+            xa = (sq - 1.0 - t) * d_recip(2.0 * sa);
+            xb = 2.0 * d_recip(sq + 1.0 - t);
+        } else {
+            xa = 2.0 * d_recip(sq + 1.0 + t);
+            xb = 2.0 * d_recip(sq + 1.0 - t);
+        }
+        const R la = d_log(xa), lb = d_log(xb);
+        a = a + r * (c.na * (la - 0.5 * xa + 0.5) + c.nb * (lb - 0.5 * xb + 0.5));
+        const R qS = (-(c.na * c.nb)) * (xa * xb);
+        g.na = r * la;
+        g.nb = r * lb;
+        g.da = (r2 * h) * qS;
+        a_eta = a_eta + ((r2 * c.da) * h1) * qS;
+    }
+    g.ceta = r * a_eta;
+    return a;
+}
+
+// adj += w * value(g)      (V: functor picking the double to use from an R-valued adjoint)
+template <class R, class V>
+PCS_DEV void adjoint_axpy(const PureCoef<double>& c, PureCoefAdj<double>& adj, const PureCoefAdj<R>& g, double w, V&& pick) {
+    adj.m += w * pick(g.m); adj.mm1 += w * pick(g.mm1); adj.ceta += w * pick(g.ceta);
+    adj.kd1 += w * pick(g.kd1); adj.kd2 += w * pick(g.kd2);
+#pragma unroll
+    for (int k = 0; k < 7; k++) { adj.ai[k] += w * pick(g.ai[k]); adj.bi[k] += w * pick(g.bi[k]); }
+    if (c.polar) {
+        adj.qm += w * pick(g.qm);
+#pragma unroll
+        for (int k = 0; k < 5; k++) adj.j1[k] += w * pick(g.j1[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) adj.j2[k] += w * pick(g.j2[k]);
+    }
+    if (c.assoc) { adj.da += w * pick(g.da); adj.na += w * pick(g.na); adj.nb += w * pick(g.nb); }
+}
 
 // WHICH: 0 vapor_pressure [Pa], 1 liquid_density [kmol/m3], 2 equilibrium_liquid_density [kmol/m3]
 template <int WHICH>
 PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv, double rl, double g[JAC_DIRS]) {
     typedef DN<double, JAC_CHUNK> G;
     constexpr int NPASS = (JAC_DIRS + JAC_CHUNK - 1) / JAC_CHUNK;
+#if PCS_JAC_ADJOINT
+    {
+        // Every property is  val = F(a_c(rho_V), a_c(rho_L), a'_c(rho_L); T, p)  with the densities fixed, so its parameter
+        // derivative is  sum_k abar_k dc_k/dtheta + explicit T / p terms  with the coefficient adjoints abar from closed-form
+        // evaluations in plain doubles (pure_a_adjoint); only the coefficient set itself is then differentiated forward, all
+        // nine directions (8 parameters, T) in ONE DN<9> pass over pure_coef -- the products abar_k c_k are accumulated as
+        // the coefficients appear, so the 33 x 9 tangents never sit in registers together.
+        PureCoef<double> c0;
+        pure_coef<double>(c0, par, T, true);
+        PureCoefAdj<double> adj;
+        adj.m = adj.mm1 = adj.ceta = adj.kd1 = adj.kd2 = adj.qm = adj.da = adj.na = adj.nb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) adj.ai[k] = adj.bi[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) adj.j1[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) adj.j2[k] = 0.0;
+        const double inv_v = 1.0 / rv, inv_l = 1.0 / rl;
+        double gT_explicit = 0.0, gP_explicit = 0.0;
+        auto value = [](double x) { return x; };
+        if (WHICH == 0) {
+            // p_sat = K (a_V/rho_V - a_L/rho_L + ln(rho_V/rho_L)) T kB/A^3,  K = -1/(1/rho_V - 1/rho_L)   (:212-215)
+            const double K = -1.0 / (inv_v - inv_l) * (T * P_UNIT);
+            PureCoefAdj<double> gg;
+            const double a_v = pure_a_adjoint<double>(c0, rv, gg);
+            adjoint_axpy(c0, adj, gg, K * inv_v, value);
+            const double a_l = pure_a_adjoint<double>(c0, rl, gg);
+            adjoint_axpy(c0, adj, gg, -K * inv_l, value);
+            gT_explicit = K * (a_v * inv_v - a_l * inv_l + log(rv * inv_l)) / T;
+        } else {
+            // liquid_density: rho - (p(rho) - p_spec)/dp (:196-199); equilibrium_liquid_density: the same with the
+            // equal-area pressure pp in place of p_spec (:228-233).  At the root the tangent of the quotient is
+            // -(dp_tan - dp_spec_tan)/dp up to a term proportional to the last Newton step (~1e-12 relative).
+            D2<double> a0 = pure_a<double, D2<double>>(c0, D2<double>(rl, 1.0, 0.0));
+            const double dp_plain = 1.0 + rl * a0.d2;
+            const double wq = -1.0 / (dp_plain * RHO_UNIT);
+            PureCoefAdj<D1s> gl;
+            pure_a_adjoint<D1s>(c0, D1s(rl, 1.0), gl);
+            // dp/dc_k = -da/dc_k + rho da'/dc_k
+            adjoint_axpy(c0, adj, gl, wq, [rl](const D1s& x) { return rl * x.d1 - x.v; });
+            if (WHICH == 1) {
+                const double p_spec = p_pa / (T * P_UNIT);
+                gP_explicit = -wq / (T * P_UNIT);
+                gT_explicit = wq * p_spec / T;
+            } else {
+                const double Kp = -1.0 / (inv_v - inv_l);
+                PureCoefAdj<double> gv;
+                pure_a_adjoint<double>(c0, rv, gv);
+                adjoint_axpy(c0, adj, gv, -wq * Kp * inv_v, value);
+                adjoint_axpy(c0, adj, gl, wq * Kp * inv_l, [](const D1s& x) { return x.v; });
+            }
+        }
+        typedef DN<double, 9> G9;
+        G9 gp[8], gT;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            gp[k].v = par[k];
+#pragma unroll
+            for (int j = 0; j < 9; j++) gp[k].e[j] = (j == k) ? 1.0 : 0.0;
+        }
+        gT.v = T;
+#pragma unroll
+        for (int j = 0; j < 9; j++) gT.e[j] = (j == 8) ? 1.0 : 0.0;
+        PureCoef<G9> c;
+        pure_coef<G9>(c, gp, gT, true);
+        G9 S = c.m * adj.m + c.mm1 * adj.mm1 + c.ceta * adj.ceta + c.kd1 * adj.kd1 + c.kd2 * adj.kd2;
+#pragma unroll
+        for (int k = 0; k < 7; k++) S = S + c.ai[k] * adj.ai[k] + c.bi[k] * adj.bi[k];
+        if (c.polar) {
+            S = S + c.qm * adj.qm;
+#pragma unroll
+            for (int k = 0; k < 5; k++) S = S + c.j1[k] * adj.j1[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) S = S + c.j2[k] * adj.j2[k];
+        }
+        if (c.assoc) S = S + c.da * adj.da + c.na * adj.na + c.nb * adj.nb;
+#pragma unroll
+        for (int d = 0; d < 9; d++) g[d] = S.e[d];
+        g[8] += gT_explicit;
+        g[9] = gP_explicit;
+        return;
+    }
+#endif
     double dp_plain = 1.0;
     if (WHICH != 0) {
         PureCoef<double> c0;

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BLOCK) void k_pure_derivatives(const double* __rest
 #define PCS_K4_BUCKET 1
 #endif
 template <int WHICH>
-__global__ __launch_bounds__(BLOCK) void k_pure_jacobian(const double* __restrict__ params,
+__global__ __launch_bounds__(BLOCK, 2) void k_pure_jacobian(const double* __restrict__ params,
                                                          const double* __restrict__ temp,
                                                          const double* __restrict__ pressure,
                                                          const double* __restrict__ rho_vl, int64_t n,
