@@ -88,7 +88,8 @@ def test_kernel_stack_frames_and_occupancy(hip_lib):
     """Compiler report of the last build (feos_torch_amd/build/resources.json).  Large per-lane stack frames make the
     runtime throttle the resident waves (the mixture Jacobian ran at 21 ms instead of 10 ms per 1e6 rows with a
     2.5-4 KB frame), so every kernel is held below 2.25 KB; the headline kernel must keep its
-    three waves per SIMD and use no stack at all."""
+    four waves per SIMD (122 VGPRs; the SLP vectoriser alone costs it one of them) and use no stack at all; the pure
+    Jacobian kernels must keep two."""
     import json
 
     from feos_torch_amd import build
@@ -102,7 +103,10 @@ def test_kernel_stack_frames_and_occupancy(hip_lib):
         limit = 3072 if ("vjp" in name or "k_gc_segment_gradient<1>" in name or "k_mixn" in name) else 2304
         assert r["scratch"] <= limit, (name, r)
     lite = [r for name, r in res.items() if "k_pure_vle<true>" in name]
-    assert len(lite) == 1 and lite[0]["scratch"] == 0 and lite[0]["occupancy"] >= 3, lite
+    assert len(lite) == 1 and lite[0]["scratch"] == 0 and lite[0]["occupancy"] >= 4, lite
+    for which in range(3):
+        jac = res[f"void k_pure_jacobian<{which}>"]
+        assert jac["occupancy"] >= 2 and jac["scratch"] <= 256, (which, jac)
     for name, r in res.items():
         if "k_pure_vle" in name or "k_pure_liquid_density" in name or name == "k_pure_derivatives":
             assert r["scratch"] == 0, (name, r)
