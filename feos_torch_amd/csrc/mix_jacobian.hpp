@@ -12,6 +12,7 @@
 // densities, so each phase needs d/dtheta of a and of ONE directional derivative of a: D1<DN<double,C>> evaluations
 // along beta (4 numbers per quantity for C = 1 instead of the 6 of a full gradient), C directions per pass.
 #pragma once
+#include "mix_adjoint.hpp"
 #include "mix_model.hpp"
 #include "mix_solver.hpp"
 
@@ -86,8 +87,42 @@ __device__ __attribute__((noinline)) void mix_coef_tangent(MixCoef<G>& c, const 
 // spec_is_vapor: the pressure functional is always taken on the VAPOUR phase (p^S for dew, p^I for
 // bubble): the liquid-phase pressure is a difference of O(0.1) terms, so its explicit parameter
 // derivative would have to cancel against w . dF/dtheta to the size of p itself.
+#ifndef PCS_MIX_ADJOINT
+#define PCS_MIX_ADJOINT 1  // coefficient adjoints (mix_adjoint.hpp) + forward tangents of the coefficient set only; 0: tangents through everything
+#endif
+#ifndef PCS_MIX_ADJ_CHUNK
+#define PCS_MIX_ADJ_CHUNK 3  // A/B 1e6 rows: 2: 2.6 ms, 3: 2.5, 4: 2.5, 5: 3.0, 7: 3.8, 10: 5.1 (spills of the pass function)
+#endif
+constexpr int MIX_ADJ_CHUNK = PCS_MIX_ADJ_CHUNK;  // parameter directions per pass over mix_coef in the adjoint form
+
+// one pass of the adjoint form: e[j] = d/dtheta_{d0+j} sum_k adj[k] c_k(theta), the coefficient set with MIX_ADJ_CHUNK tangents
+__device__ __attribute__((noinline)) void mix_adjoint_pass(const double* __restrict__ par, double k0, double k1, double T, int d0,
+                                                           const double* adj, int adj_stride, double* __restrict__ e) {
+    typedef DN<double, MIX_ADJ_CHUNK> GA;
+    GA gp[16], gk0, gk1, gT;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        gp[k].v = par[k];
+#pragma unroll
+        for (int j = 0; j < MIX_ADJ_CHUNK; j++) gp[k].e[j] = (d0 + j == k) ? 1.0 : 0.0;
+    }
+    gk0.v = k0; gk1.v = k1; gT.v = T;
+#pragma unroll
+    for (int j = 0; j < MIX_ADJ_CHUNK; j++) {
+        gk0.e[j] = (d0 + j == 16) ? 1.0 : 0.0;
+        gk1.e[j] = (d0 + j == 17) ? 1.0 : 0.0;
+        gT.e[j] = (d0 + j == 18) ? 1.0 : 0.0;
+    }
+    MixCoef<GA> cg;
+    mix_coef<GA>(cg, gp, gk0, gk1, gT);
+    const GA S = mix_adjoint_contract(cg, adj, adj_stride);
+#pragma unroll
+    for (int j = 0; j < MIX_ADJ_CHUNK; j++) e[j] = S.e[j];
+}
+
+// adj: lane-strided scratch of ADJ_SLOTS doubles (adj[k * adj_stride]), LDS in k_mix_jacobian (unused by the tangent form)
 PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, double s0, double s1, double i0,
-                          double i1, bool spec_is_vapor, double* __restrict__ g) {
+                          double i1, bool spec_is_vapor, double* __restrict__ g, double* adj, int adj_stride) {
     MixModelD m;
     mix_coef<double>(m.c, par, k0, k1, T);
     PhaseEval s = phase_eval(m, s0, s1);
@@ -134,6 +169,35 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
         alpha[0] = w[2];   beta0[0] = -w[2] * s0 - w[0]; beta1[0] = -w[2] * s1 - w[1];
         alpha[1] = -u;     beta0[1] = u * i0 + w[0];     beta1[1] = u * i1 + w[1];
     }
+#if PCS_MIX_ADJOINT
+    {
+        // dp/dtheta = T kB/A^3 sum_k abar_k dc_k/dtheta (+ p/T for theta = T) with the coefficient adjoints
+        // abar = sum over the phases of d/dc [alpha a + beta . grad a], closed form (mix_adjoint.hpp)
+#pragma unroll
+        for (int k = 0; k < ADJ_SLOTS; k++) adj[k * adj_stride] = 0.0;
+#pragma unroll 1
+        for (int ph = 0; ph < 2; ph++) {
+            const double q0 = ph == 0 ? s0 : i0, q1 = ph == 0 ? s1 : i1;
+            const double al = ph == 0 ? alpha[0] : alpha[1], b0 = ph == 0 ? beta0[0] : beta0[1], b1 = ph == 0 ? beta1[0] : beta1[1];
+            mix_a_adjoint(m.c, q0, q1, b0, b1, al, adj, adj_stride);
+        }
+#pragma unroll 1
+        for (int d0 = 0; d0 < MIX_DIRS; d0 += MIX_ADJ_CHUNK) {
+            double e[MIX_ADJ_CHUNK];
+            mix_adjoint_pass(par, k0, k1, T, d0, adj, adj_stride, e);
+#pragma unroll
+            for (int j = 0; j < MIX_ADJ_CHUNK; j++) {
+                const int d = d0 + j;
+                if (d < MIX_DIRS) {
+                    double val = e[j] * T * P_UNIT;
+                    if (d == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
+                    if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
+                    g[d] = val;
+                }
+            }
+        }
+    }
+#else
     constexpr int NPASS = (MIX_DIRS + MIX_CHUNK - 1) / MIX_CHUNK;
     // directions whose derivative is structurally zero: a dipole moment of 0 (the term is quadratic in it), every
     // association parameter when no component associates (the term is absent), eps_AiBj unless it is in use
@@ -185,6 +249,7 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
             if (d >= 0) g[d] = val;
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -462,6 +462,9 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* 
     // bucketed inside the workgroup as in k_mix_bubble_dew
     __shared__ int perm[MBLOCK];
     __shared__ int bins[MIX_BINS + 1];
+#if PCS_MIX_ADJOINT
+    __shared__ double adj_lds[ADJ_SLOTS * MBLOCK];  // coefficient adjoints of this lane's row: adj_lds[k * MBLOCK + t]
+#endif
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * MBLOCK;
     int64_t i;
@@ -495,8 +498,13 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* 
     load_mix_row(params, kij, i, par, k0, k1);
     double4 r = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
     double* g = jac + MIX_DIRS * i;
-    if (dew) mix_jacobian(par, k0, k1, temp[i], r.x, r.y, r.z, r.w, true, g);
-    else mix_jacobian(par, k0, k1, temp[i], r.z, r.w, r.x, r.y, false, g);
+#if PCS_MIX_ADJOINT
+    double* adj = adj_lds + t;
+#else
+    double* adj = nullptr;
+#endif
+    if (dew) mix_jacobian(par, k0, k1, temp[i], r.x, r.y, r.z, r.w, true, g, adj, MBLOCK);
+    else mix_jacobian(par, k0, k1, temp[i], r.z, r.w, r.x, r.y, false, g, adj, MBLOCK);
 }
 
 // vector-Jacobian product of PcSaftMix.derivatives (autograd of derivatives / helmholtz_energy_density)

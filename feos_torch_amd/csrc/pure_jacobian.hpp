@@ -36,16 +36,6 @@ template <class R>
 struct PureCoefAdj {
     R m, mm1, ceta, ai[7], bi[7], kd1, kd2, j1[5], j2[4], qm, da, na, nb;
 };
-template <int N, class R>
-PCS_DEV void poly_and_derivative(const double* coef, const R& x, R& p, R& dp) {  // sum coef[k] x^k and its x-derivative
-    p = x * coef[N - 1] + coef[N - 2];
-    dp = x * ((N - 1) * coef[N - 1]) + (N - 2) * coef[N - 2];
-#pragma unroll
-    for (int k = N - 3; k >= 0; k--) {
-        p = p * x + coef[k];
-        if (k >= 1) dp = dp * x + k * coef[k];
-    }
-}
 template <class R>
 PCS_DEV R pure_a_adjoint(const PureCoef<double>& c, const R& r, PureCoefAdj<R>& g) {
     const R eta = r * c.ceta, r2 = r * r;

@@ -170,6 +170,17 @@ PCS_DEV D1s horner_eta(const double* coef, const D1s& x) {
     return D1s(p, d1 * x.d1);
 }
 
+// sum coef[k] x^k and its x-derivative in R arithmetic (the coefficient adjoints of the Jacobian kernels)
+template <int N, class R>
+PCS_DEV void poly_and_derivative(const double* coef, const R& x, R& p, R& dp) {  // sum coef[k] x^k and its x-derivative
+    p = x * coef[N - 1] + coef[N - 2];
+    dp = x * ((N - 1) * coef[N - 1]) + (N - 2) * coef[N - 2];
+#pragma unroll
+    for (int k = N - 3; k >= 0; k--) {
+        p = p * x + coef[k];
+        if (k >= 1) dp = dp * x + k * coef[k];
+    }
+}
 template <class R>
 PCS_DEV R site_term(const R& x) {  // ln x - x/2 + 1/2   (:176)
     return d_log(x) - 0.5 * x + 0.5;
