@@ -120,6 +120,114 @@ __device__ __attribute__((noinline)) void mix_adjoint_pass(const double* __restr
     for (int j = 0; j < MIX_ADJ_CHUNK; j++) e[j] = S.e[j];
 }
 
+// Gradient of S(theta) = sum_k adj[k] c_k(theta) w.r.t. the 19 inputs, block by block: every block of mix_coef (mix_model.hpp)
+// depends on a few inputs only -- a component's (m, sigma, eps, T); the dispersion aggregates on 8; the dipole polynomials
+// on 9; the association strengths on 14 -- so each is differentiated forward with just those seeded (DN<4>, DN<8>, DN<9>,
+// DN<14> over a small function) instead of 19 directions through the whole coefficient set (7 DN<3> passes: 19 k
+// instructions per row; this form: 1.5 k for a non-polar non-associating row, ~6 k with both).
+#ifndef PCS_MIX_COEF_BLOCKS
+#define PCS_MIX_COEF_BLOCKS 1
+#endif
+template <class G> struct MixCompOut { G m[2], mm1[2], d[2], zk[4][2]; };
+template <class G> struct MixDispOut { G A[3], B[3]; };
+template <class G> struct MixAssocIO { int acls; G na[2], nb[2], d[2], dij[3], S[3]; };
+template <int N>
+PCS_DEV void seed_inputs(DN<double, N>* x, const double* val) {
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        x[k].v = val[k];
+#pragma unroll
+        for (int j = 0; j < N; j++) x[k].e[j] = (j == k) ? 1.0 : 0.0;
+    }
+}
+__device__ __attribute__((noinline)) void mix_coef_gradient(const double* __restrict__ par, double k0, double k1, double T,
+                                                            const double* adj, int st, double* __restrict__ grad) {
+#define PCS_AD(slot) adj[(slot) * st]
+#pragma unroll
+    for (int d = 0; d < MIX_DIRS; d++) grad[d] = 0.0;
+    // components
+#pragma unroll 1
+    for (int i = 0; i < 2; i++) {
+        typedef DN<double, 4> G;
+        const double val[4] = {par[8 * i], par[8 * i + 1], par[8 * i + 2], T};
+        G x[4];
+        seed_inputs<4>(x, val);
+        const G rT = d_recip(x[3]);
+        MixCompOut<G> o;
+        mix_coef_component(o, i, x[0], x[1], x[2], rT);
+        G S = o.m[i] * PCS_AD(ADJ_M + i) + o.mm1[i] * PCS_AD(ADJ_MM1 + i) + o.d[i] * PCS_AD(ADJ_D + i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) S = S + o.zk[k][i] * PCS_AD(ADJ_ZK + 2 * k + i);
+        grad[8 * i] += S.e[0];
+        grad[8 * i + 1] += S.e[1];
+        grad[8 * i + 2] += S.e[2];
+        grad[18] += S.e[3];
+    }
+    // dispersion aggregates: m0, m1, sigma0, sigma1, eps0, eps1, k_ij, T
+    {
+        typedef DN<double, 8> G;
+        const double val[8] = {par[0], par[8], par[1], par[9], par[2], par[10], k0, T};
+        G x[8];
+        seed_inputs<8>(x, val);
+        const G rT = d_recip(x[7]);
+        MixDispOut<G> o;
+        mix_coef_dispersion(o, &x[0], &x[2], &x[4], x[6], rT);
+        G S = o.A[0] * PCS_AD(ADJ_A) + o.B[0] * PCS_AD(ADJ_B);
+#pragma unroll
+        for (int q = 1; q < 3; q++) S = S + o.A[q] * PCS_AD(ADJ_A + q) + o.B[q] * PCS_AD(ADJ_B + q);
+        const int idx[8] = {0, 8, 1, 9, 2, 10, 16, 18};
+#pragma unroll
+        for (int k = 0; k < 8; k++) grad[idx[k]] += S.e[k];
+    }
+    // dipole polynomials: m0, m1, sigma0, sigma1, eps0, eps1, mu0, mu1, T
+    if (par[3] != 0.0 || par[11] != 0.0) {
+        typedef DN<double, 9> G;
+        const double val[9] = {par[0], par[8], par[1], par[9], par[2], par[10], par[3], par[11], T};
+        G x[9];
+        seed_inputs<9>(x, val);
+        const G rT = d_recip(x[8]);
+        G mu2t[2] = {mix_mu2t(x[6], x[0], rT), mix_mu2t(x[7], x[1], rT)};
+        G pj[3][5], tj[4][4];
+        dipole_coefficients<G>(pj, tj, &x[0], &x[2], &x[4], mu2t, rT);
+        G S(0.0);
+#pragma unroll
+        for (int pr = 0; pr < 3; pr++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) S = S + pj[pr][k] * PCS_AD(ADJ_PJ + 5 * pr + k);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) S = S + tj[t][k] * PCS_AD(ADJ_TJ + 4 * t + k);
+        const int idx[9] = {0, 8, 1, 9, 2, 10, 3, 11, 18};
+#pragma unroll
+        for (int k = 0; k < 9; k++) grad[idx[k]] += S.e[k];
+    }
+    // association: sigma0, sigma1, eps0, eps1, kappa0, kappa1, eps_ab0, eps_ab1, na0, na1, nb0, nb1, eps_AiBj, T
+    const int acls = mix_assoc_class(par[6], par[7], par[14], par[15]);
+    if (acls != ASSOC_NONE) {
+        typedef DN<double, 14> G;
+        const double val[14] = {par[1], par[9], par[2], par[10], par[4], par[12], par[5], par[13], par[6], par[14], par[7], par[15], k1, T};
+        G x[14];
+        seed_inputs<14>(x, val);
+        const G rT = d_recip(x[13]);
+        MixAssocIO<G> o;
+        o.acls = acls;
+        o.na[0] = x[8]; o.na[1] = x[9]; o.nb[0] = x[10]; o.nb[1] = x[11];
+        o.d[0] = mix_diameter(x[0], x[2], rT);
+        o.d[1] = mix_diameter(x[1], x[3], rT);
+        mix_coef_assoc(o, &x[0], &x[4], &x[6], x[12], rT);
+        G S = o.na[0] * PCS_AD(ADJ_NA) + o.na[1] * PCS_AD(ADJ_NA + 1) + o.nb[0] * PCS_AD(ADJ_NB) + o.nb[1] * PCS_AD(ADJ_NB + 1);
+        const int nq = acls == ASSOC_SELF ? 1 : 3;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (q < nq) S = S + o.dij[q] * PCS_AD(ADJ_DIJ + q) + o.S[q] * PCS_AD(ADJ_S + q);
+        const int idx[14] = {1, 9, 2, 10, 4, 12, 5, 13, 6, 14, 7, 15, 17, 18};
+#pragma unroll
+        for (int k = 0; k < 14; k++) grad[idx[k]] += S.e[k];
+    }
+#undef PCS_AD
+}
+
 // adj: lane-strided scratch of ADJ_SLOTS doubles (adj[k * adj_stride]), LDS in k_mix_jacobian (unused by the tangent form)
 PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, double s0, double s1, double i0,
                           double i1, bool spec_is_vapor, double* __restrict__ g, double* adj, int adj_stride) {
@@ -181,6 +289,17 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
             const double al = ph == 0 ? alpha[0] : alpha[1], b0 = ph == 0 ? beta0[0] : beta0[1], b1 = ph == 0 ? beta1[0] : beta1[1];
             mix_a_adjoint(m.c, q0, q1, b0, b1, al, adj, adj_stride);
         }
+#if PCS_MIX_COEF_BLOCKS
+        double e[MIX_DIRS];
+        mix_coef_gradient(par, k0, k1, T, adj, adj_stride, e);
+#pragma unroll
+        for (int d = 0; d < MIX_DIRS; d++) {
+            double val = e[d] * T * P_UNIT;
+            if (d == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
+            if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
+            g[d] = val;
+        }
+#else
 #pragma unroll 1
         for (int d0 = 0; d0 < MIX_DIRS; d0 += MIX_ADJ_CHUNK) {
             double e[MIX_ADJ_CHUNK];
@@ -196,6 +315,7 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
                 }
             }
         }
+#endif
     }
 #else
     constexpr int NPASS = (MIX_DIRS + MIX_CHUNK - 1) / MIX_CHUNK;

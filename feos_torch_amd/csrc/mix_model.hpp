@@ -86,75 +86,102 @@ PCS_DEV void dipole_coefficients(P pj[3][5], P tj[4][4], const P* m, const P* si
     }
 }
 
+// The coefficient set in blocks, each a function of its own few inputs (mix_coef below calls them in turn; the gradient
+// kernels differentiate them one by one with just those inputs seeded, mix_jacobian.hpp).
+// segment diameter (:33)
+template <class P>
+PCS_DEV P mix_diameter(const P& sig, const P& eps, const P& rT) { return sig * (1.0 - 0.12 * d_exp(-3.0 * (eps * rT))); }
+// component i: m, mm1, d, zk
+template <class C, class P>
+PCS_DEV void mix_coef_component(C& c, int i, const P& m, const P& sig, const P& eps, const P& rT) {
+    c.m[i] = m;
+    c.mm1[i] = m - 1.0;
+    c.d[i] = mix_diameter(sig, eps, rT);
+    P md = c.m[i] * FRAC_PI_6;
+    c.zk[0][i] = md;
+    c.zk[1][i] = md * c.d[i];
+    c.zk[2][i] = md * (c.d[i] * c.d[i]);
+    c.zk[3][i] = md * (c.d[i] * c.d[i] * c.d[i]);
+}
+// dispersion aggregates (:78-90)
+template <class C, class P>
+PCS_DEV void mix_coef_dispersion(C& c, const P* m, const P* sig, const P* eps, const P& kij0, const P& rT) {
+    P s3[2] = {sig[0] * sig[0] * sig[0], sig[1] * sig[1] * sig[1]};
+    P e01 = d_sqrt(eps[0] * eps[1]) * rT * (1.0 - kij0);
+    P s01 = 0.5 * (sig[0] + sig[1]);
+    P s01_3 = s01 * s01 * s01;
+    P e00 = eps[0] * rT, e11 = eps[1] * rT;
+    c.A[0] = (m[0] * m[0]) * (e00 * s3[0]);
+    c.A[1] = 2.0 * ((m[0] * m[1]) * (e01 * s01_3));
+    c.A[2] = (m[1] * m[1]) * (e11 * s3[1]);
+    c.B[0] = c.A[0] * e00;
+    c.B[1] = c.A[1] * e01;
+    c.B[2] = c.A[2] * e11;
+}
+// sigma^3 eps mu2 / T with mu2 = mu^2/(m sigma^3 eps) * MU2_UNIT  (:17-22, :163)
+template <class P>
+PCS_DEV P mix_mu2t(const P& mu, const P& m, const P& rT) { return (mu * mu) * (d_recip(m) * rT) * MU2_UNIT; }
+// association class from the site counts (:118-152)
+PCS_DEV int mix_assoc_class(double na0, double nb0, double na1, double nb1) {
+    const int associating = (na0 + nb0 != 0.0) + (na1 + nb1 != 0.0);
+    const int self_assoc = (na0 * nb0 != 0.0) + (na1 * nb1 != 0.0);
+    int acls = ASSOC_NONE;
+    if (associating == 1 && self_assoc == 1) acls = ASSOC_SELF;
+    if (associating == 2 && self_assoc == 2) acls = ASSOC_CROSS;
+    if (associating == 2 && self_assoc == 1) acls = ASSOC_INDUCED;
+    return acls;
+}
+// association strengths and contact distances for class c.acls; c.na, c.nb, c.d must be set
+template <class C, class P>
+PCS_DEV void mix_coef_assoc(C& c, const P* sig, const P* kap, const P* eab, const P& kij1, const P& rT) {
+    if (c.acls == ASSOC_SELF) {
+        // site-weighted sigma and d, summed kappa and eps (:211-218)
+        P kp = kap[0] + kap[1];
+        P ea = eab[0] + eab[1];
+        P rna = d_recip(c.na[0] + c.na[1]);
+        P sg = (c.na[0] * sig[0] + c.na[1] * sig[1]) * rna;
+        P dd = (c.na[0] * c.d[0] + c.na[1] * c.d[1]) * rna;
+        c.dij[0] = 0.5 * dd;
+        c.S[0] = (sg * sg * sg) * kp * (d_exp(ea * rT) - 1.0);
+    } else if (c.acls == ASSOC_CROSS || c.acls == ASSOC_INDUCED) {
+        c.dij[0] = 0.5 * c.d[0];
+        c.dij[1] = (c.d[0] * c.d[1]) * d_recip(c.d[0] + c.d[1]);
+        c.dij[2] = 0.5 * c.d[1];
+        P e_cross = 0.5 * (eab[0] + eab[1]);
+        if (c.acls == ASSOC_CROSS && re(kij1) != 0.0) e_cross = kij1;  // :509-514
+        P ss = sig[0] * sig[1];
+        c.S[0] = (sig[0] * sig[0] * sig[0]) * kap[0] * (d_exp(eab[0] * rT) - 1.0);
+        c.S[1] = (ss * d_sqrt(ss)) * d_sqrt(kap[0] * kap[1]) * (d_exp(e_cross * rT) - 1.0);
+        c.S[2] = (sig[1] * sig[1] * sig[1]) * kap[1] * (d_exp(eab[1] * rT) - 1.0);
+    }
+}
+
 // par = [2][8] rows (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb); kij0 = k_ij,
 // kij1 = explicit eps_AiBj/k or 0 (src/pcsaft.rs:163).
 template <class P>
 PCS_DEV void mix_coef(MixCoef<P>& c, const P* par, const P& kij0, const P& kij1, const P& T) {
     P rT = d_recip(T);
-    P sig[2], eps[2], s3[2], mu2t[2];
+    P sig[2], eps[2], mu2t[2], kap[2], eab[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const P* p = par + 8 * i;
-        c.m[i] = p[0];
-        c.mm1[i] = p[0] - 1.0;
         sig[i] = p[1];
         eps[i] = p[2];
-        s3[i] = sig[i] * sig[i] * sig[i];
-        c.d[i] = sig[i] * (1.0 - 0.12 * d_exp(-3.0 * (eps[i] * rT)));  // :33
-        P md = c.m[i] * FRAC_PI_6;
-        c.zk[0][i] = md;
-        c.zk[1][i] = md * c.d[i];
-        c.zk[2][i] = md * (c.d[i] * c.d[i]);
-        c.zk[3][i] = md * (c.d[i] * c.d[i] * c.d[i]);
-        // sigma^3 eps mu2 / T with mu2 = mu^2/(m sigma^3 eps) * MU2_UNIT  (:17-22, :163)
-        mu2t[i] = (p[3] * p[3]) * (d_recip(p[0]) * rT) * MU2_UNIT;
+        mix_coef_component(c, i, p[0], sig[i], eps[i], rT);
+        mu2t[i] = mix_mu2t(p[3], p[0], rT);
+        kap[i] = p[4];
+        eab[i] = p[5];
         c.na[i] = p[6];
         c.nb[i] = p[7];
     }
-    // dispersion (:78-90)
-    P e01 = d_sqrt(eps[0] * eps[1]) * rT * (1.0 - kij0);
-    P s01 = 0.5 * (sig[0] + sig[1]);
-    P s01_3 = s01 * s01 * s01;
-    P e00 = eps[0] * rT, e11 = eps[1] * rT;
-    c.A[0] = (c.m[0] * c.m[0]) * (e00 * s3[0]);
-    c.A[1] = 2.0 * ((c.m[0] * c.m[1]) * (e01 * s01_3));
-    c.A[2] = (c.m[1] * c.m[1]) * (e11 * s3[1]);
-    c.B[0] = c.A[0] * e00;
-    c.B[1] = c.A[1] * e01;
-    c.B[2] = c.A[2] * e11;
+    mix_coef_dispersion(c, c.m, sig, eps, kij0, rT);
 
     // dipoles (:156-208)
     c.polar = (re(par[3]) != 0.0) || (re(par[8 + 3]) != 0.0);
     if (c.polar) dipole_coefficients<P>(c.pj, c.tj, c.m, sig, eps, mu2t, rT);
 
-    // association (:118-152)
-    const int associating = (re(c.na[0]) + re(c.nb[0]) != 0.0) + (re(c.na[1]) + re(c.nb[1]) != 0.0);
-    const int self_assoc = (re(c.na[0]) * re(c.nb[0]) != 0.0) + (re(c.na[1]) * re(c.nb[1]) != 0.0);
-    c.acls = ASSOC_NONE;
-    if (associating == 1 && self_assoc == 1) c.acls = ASSOC_SELF;
-    if (associating == 2 && self_assoc == 2) c.acls = ASSOC_CROSS;
-    if (associating == 2 && self_assoc == 1) c.acls = ASSOC_INDUCED;
-    if (c.acls == ASSOC_SELF) {
-        // site-weighted sigma and d, summed kappa and eps (:211-218)
-        P kap = par[4] + par[8 + 4];
-        P eab = par[5] + par[8 + 5];
-        P rna = d_recip(c.na[0] + c.na[1]);
-        P sg = (c.na[0] * sig[0] + c.na[1] * sig[1]) * rna;
-        P dd = (c.na[0] * c.d[0] + c.na[1] * c.d[1]) * rna;
-        c.dij[0] = 0.5 * dd;
-        c.S[0] = (sg * sg * sg) * kap * (d_exp(eab * rT) - 1.0);
-    } else if (c.acls == ASSOC_CROSS || c.acls == ASSOC_INDUCED) {
-        const P &k0 = par[4], &k1 = par[8 + 4], &ea0 = par[5], &ea1 = par[8 + 5];
-        c.dij[0] = 0.5 * c.d[0];
-        c.dij[1] = (c.d[0] * c.d[1]) * d_recip(c.d[0] + c.d[1]);
-        c.dij[2] = 0.5 * c.d[1];
-        P e_cross = 0.5 * (ea0 + ea1);
-        if (c.acls == ASSOC_CROSS && re(kij1) != 0.0) e_cross = kij1;  // :509-514
-        P ss = sig[0] * sig[1];
-        c.S[0] = s3[0] * k0 * (d_exp(ea0 * rT) - 1.0);
-        c.S[1] = (ss * d_sqrt(ss)) * d_sqrt(k0 * k1) * (d_exp(e_cross * rT) - 1.0);
-        c.S[2] = s3[1] * k1 * (d_exp(ea1 * rT) - 1.0);
-    }
+    c.acls = mix_assoc_class(re(c.na[0]), re(c.nb[0]), re(c.na[1]), re(c.nb[1]));
+    mix_coef_assoc(c, sig, kap, eab, kij1, rT);
 }
 
 // ---- association pieces --------------------------------------------------------------------
