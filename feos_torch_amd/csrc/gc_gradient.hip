@@ -87,6 +87,154 @@ __device__ __attribute__((noinline)) void gc_finish_tangent(GcCoef<G>& c, const 
     gc_finish<G, G>(c, g, phi0, phi1, G(rT));
 }
 
+#ifndef PCS_GC_ADJOINT
+#define PCS_GC_ADJOINT 1  // MODE 0: coefficient adjoints (mix_adjoint.hpp) instead of 13 dual-number passes through both phases
+#endif
+
+// Coefficient adjoints of the gc Helmholtz energy along (q, b), as mix_a_adjoint (mix_adjoint.hpp): shared packing / hard
+// sphere / dispersion / dipole part, the bond-based chain term (only its packing-sum dependence here: the bond diameters
+// are part (3) of the kernel) and gc's association forms -- one site of each kind per molecule (:309-330, :358-380), whose
+// energy is stationary in the site fractions:  d/dDelta = -rho_a^2 X^2 (self),  d/dDelta_ij = -rho_i rho_j X_i X_j (cross);
+// induced association as in the binary model.
+__device__ __attribute__((noinline)) void gc_a_adjoint(const GcCoef<double>& c, double q0, double q1, double b0, double b1, double alpha,
+                                                       double* out, int stride) {
+    typedef D1s R;
+    AdjCtx x;
+    adjoint_core(c, q0, q1, b0, b1, alpha, out, stride, x);
+    const R &r0 = x.r0, &r1 = x.r1;
+    {
+        const R cc = x.zeta2 * x.z3m2;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const R& ri = i == 0 ? r0 : r1;
+#pragma unroll 1
+            for (int e = 0; e < GC_MAXE; e++) {
+                const int slot = (i * GC_MAXE + e) * c.stride;
+                const double n = c.bond_cnt[slot];
+                if (n == 0.0) continue;
+                const double dab = c.bond_dab[slot];
+                const R cd = cc * dab;
+                const R g = x.z3m1 + 3.0 * cd + 2.0 * ((cd * cd) * x.omz);
+                const R pre = (ri * n) * d_recip(g);
+                x.dz2 = x.dz2 - pre * ((3.0 * dab + (4.0 * dab) * (cd * x.omz)) * x.z3m2);
+                x.dz3 = x.dz3 - pre * (x.z3m2 + 6.0 * (cd * x.z3m1) + 6.0 * (cd * cd));
+            }
+        }
+    }
+    if (c.acls != ASSOC_NONE) {
+        const int nq = c.acls == ASSOC_SELF ? 1 : 3;
+        AdjDelta dl;
+        adjoint_delta(c, x, nq, dl);
+        R dD[3];
+        if (c.acls == ASSOC_SELF) {
+            const R rho_a = r0 * c.isa[0] + r1 * c.isa[1];
+            const R xa = 2.0 * d_recip(d_sqrt(1.0 + 4.0 * (dl.D[0] * rho_a)) + 1.0);
+            dD[0] = -((rho_a * rho_a) * (xa * xa));
+        } else if (c.acls == ASSOC_CROSS) {
+            const R d00 = dl.D[0] * r0, d01 = dl.D[1] * r1, d10 = dl.D[1] * r0, d11 = dl.D[2] * r1;
+            const double e00 = re(d00), e01 = re(d01), e10 = re(d10), e11 = re(d11);
+            double x0 = 0.2, x1 = 0.2;  // real parts exactly as gc_a
+            for (int it = 0; it < 200; it++) {
+                double s0, s1;
+                gc_cross_step<double>(x0, x1, e00, e01, e10, e11, s0, s1);
+                double n0 = x0 - s0, n1 = x1 - s1;
+                if (!(n0 > 0.0 && n0 <= 1.5 && n1 > 0.0 && n1 <= 1.5)) {
+                    if (it < 60 && is_finite_bits(s0) && is_finite_bits(s1)) {
+                        n0 = fmin(x0 * exp(fmin(fmax(-s0 / x0, -3.0), 3.0)), 1.0);
+                        n1 = fmin(x1 * exp(fmin(fmax(-s1 / x1, -3.0), 3.0)), 1.0);
+                    } else {
+                        n0 = 1.0 / (1.0 + x0 * e00 + x1 * e01);
+                        n1 = 1.0 / (1.0 + x0 * e10 + x1 * e11);
+                    }
+                }
+                bool conv = fabs(n0 - x0) <= 1e-12 * x0 && fabs(n1 - x1) <= 1e-12 * x1;
+                x0 = n0;
+                x1 = n1;
+                if (conv) break;
+            }
+            R xa0(x0), xa1(x1);
+            gc_cross_refine(xa0, xa1, d00, d01, d10, d11);
+            dD[0] = -((r0 * r0) * (xa0 * xa0));
+            dD[1] = -(2.0 * ((r0 * r1) * (xa0 * xa1)));
+            dD[2] = -((r1 * r1) * (xa1 * xa1));
+        } else {
+            R dn[4];
+            induced_assoc_adjoint(c.na[0], c.na[1], c.nb[0], c.nb[1], r0, r1, dl.D[0], dl.D[1], dl.D[2], dn, dD);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                out[(ADJ_NA + k) * stride] += alpha * dn[k].v + dn[k].d1;
+                out[(ADJ_NB + k) * stride] += alpha * dn[2 + k].v + dn[2 + k].d1;
+            }
+        }
+        adjoint_delta_chain(c, x, nq, dl, dD, alpha, out, stride);
+    }
+    adjoint_flush(x, alpha, out, stride);
+}
+
+// From the coefficient adjoints to the 13 molecule-level sums of both molecules: val[q][j] = d/d(sum q of molecule j) of
+// sum_k adj[k] c_k.  The packing sums are linear (gc_finish); the dipole polynomials depend on (M, S3, EK, MU) and the
+// association strengths on (sa, ea, ka, eab, na, nb) of both molecules: those two blocks are differentiated forward with
+// just their inputs seeded.
+__device__ __attribute__((noinline)) void gc_finish_gradient(const GcMol<double, double>& ml, int acls, bool polar, double rT, const double* adj,
+                                                             int st, double* __restrict__ val /* [Q_COUNT][2] */) {
+#define PCS_AD(slot) adj[(slot) * st]
+#pragma unroll
+    for (int k = 0; k < Q_COUNT * 2; k++) val[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        val[Q_M * 2 + j] = PCS_AD(ADJ_M + j) + FRAC_PI_6 * PCS_AD(ADJ_ZK + j);
+#pragma unroll
+        for (int k = 1; k < 4; k++) val[(Q_Z1 + k - 1) * 2 + j] = FRAC_PI_6 * PCS_AD(ADJ_ZK + 2 * k + j);
+    }
+    if (polar) {
+        typedef DN<double, 8> G;  // M0, M1, S3_0, S3_1, EK0, EK1, MU0, MU1
+        const double v[8] = {ml.M[0], ml.M[1], ml.S3[0], ml.S3[1], ml.EK[0], ml.EK[1], ml.MU[0], ml.MU[1]};
+        G x[8];
+        seed_inputs<8>(x, v);
+        G pj[3][5], tj[4][4];
+        gc_dipole_block<G, G>(pj, tj, &x[0], &x[2], &x[4], &x[6], G(rT));
+        G S(0.0);
+#pragma unroll
+        for (int pr = 0; pr < 3; pr++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) S = S + pj[pr][k] * PCS_AD(ADJ_PJ + 5 * pr + k);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) S = S + tj[t][k] * PCS_AD(ADJ_TJ + 4 * t + k);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            val[Q_M * 2 + j] += S.e[j];
+            val[Q_S3 * 2 + j] += S.e[2 + j];
+            val[Q_EK * 2 + j] += S.e[4 + j];
+            val[Q_MU * 2 + j] += S.e[6 + j];
+        }
+    }
+    if (acls != ASSOC_NONE) {
+        typedef DN<double, 8> G;  // sa0, sa1, ea0, ea1, ka0, ka1, eab0, eab1
+        const double v[8] = {ml.sa[0], ml.sa[1], ml.ea[0], ml.ea[1], ml.ka[0], ml.ka[1], ml.eab[0], ml.eab[1]};
+        G x[8];
+        seed_inputs<8>(x, v);
+        G dij[3], Sx[3];
+        gc_assoc_block<G, G>(acls, dij, Sx, &x[0], &x[2], &x[4], &x[6], G(rT));
+        const int nq = acls == ASSOC_SELF ? 1 : 3;
+        G S(0.0);
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (q < nq) S = S + dij[q] * PCS_AD(ADJ_DIJ + q) + Sx[q] * PCS_AD(ADJ_S + q);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            val[Q_SA * 2 + j] = S.e[j];
+            val[Q_EA * 2 + j] = S.e[2 + j];
+            val[Q_KA * 2 + j] = S.e[4 + j];
+            val[Q_EAB * 2 + j] = S.e[6 + j];
+            val[Q_NA * 2 + j] = PCS_AD(ADJ_NA + j);  // the site counts enter gc_a directly (induced association only)
+            val[Q_NB * 2 + j] = PCS_AD(ADJ_NB + j);
+        }
+    }
+#undef PCS_AD
+}
+
 // the functional whose table gradient is taken: MODE 0 = bubble / dew pressure (two phases, D1 probes along beta),
 // MODE 1 = L = ga a + gp p + gmu . mu + gv . v of `derivatives` (one point, T2 probes)
 template <int MODE, class X> struct ProbeT { typedef D1<X> type; };
@@ -231,8 +379,66 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
         // per-row NaN of pcs_gc_jacobian
         const double wrow = MODE == 0 ? (ok ? (gout ? gout[i] : 1.0) * (T * P_UNIT) : nanv) : 1.0;
 
-        // ---- (1) molecule-level sums: dual-number passes -------------------------------------------------------
-        {
+        // chain from a molecule-level sum (quantity q of molecule j, gq = weight x d functional / d sum) to the segment
+        // parameters of that molecule's entries
+        auto chain = [&](int q, int j, double gq) {
+#pragma unroll 1
+            for (int e = 0; e < GC_MAXE; e++) {
+                const int cnt = row[16 + j * GC_MAXE + e];
+                if (cnt == 0) continue;
+                const int a = row[j * GC_MAXE + e];
+                const double* p = tb.seg + 8 * a;
+                double* ga = acc + 8 * a;
+                const double gn = gq * cnt;
+                if (q == Q_M) {
+                    lds_add(ga + 0, gn);
+                } else if (q <= Q_Z3) {
+                    double d, ds, de;
+                    diameter_grad(p, rT, d, ds, de);
+                    const int k = q - Q_Z1 + 1;                                   // Z_k = sum n m d^k
+                    const double dk1 = (k == 1) ? 1.0 : (k == 2 ? d : d * d);     // d^(k-1)
+                    lds_add(ga + 0, gn * dk1 * d);
+                    const double t = gn * p[0] * (k * dk1);
+                    lds_add(ga + 1, t * ds);
+                    lds_add(ga + 2, t * de);
+                } else if (q == Q_S3) {
+                    lds_add(ga + 0, gn * p[1] * p[1] * p[1]);
+                    lds_add(ga + 1, gn * p[0] * 3.0 * p[1] * p[1]);
+                } else if (q == Q_EK) {
+                    lds_add(ga + 0, gn * p[2]);
+                    lds_add(ga + 2, gn * p[0]);
+                } else if (q == Q_MU) {
+                    lds_add(ga + 3, gn * 2.0 * p[3]);
+                } else if (q == Q_SA) {
+                    lds_add(ga + 1, gn * sgn_d(p[4] * p[5]));
+                } else if (q == Q_EA) {
+                    lds_add(ga + 2, gn * sgn_d(p[4] * p[5]));
+                } else {
+                    lds_add(ga + (q - Q_KA + 4), gn);  // kappa_ab, epsilon_k_ab, na, nb: plain sums
+                }
+            }
+        };
+        // ---- (1) molecule-level sums -------------------------------------------------------------------------------
+        if constexpr (MODE == 0 && PCS_GC_ADJOINT) {
+            // coefficient adjoints of both phases (closed form), then their chain to the 26 sums
+            double* adj = reinterpret_cast<double*>(gbonds) + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < ADJ_SLOTS; k++) adj[k * GSBLOCK] = 0.0;
+#pragma unroll 1
+            for (int pt = 0; pt < 2; pt++)
+                gc_a_adjoint(m.c, pt == 0 ? s0 : i0, pt == 0 ? s1 : i1, pt == 0 ? beta0[0] : beta0[1], pt == 0 ? beta1[0] : beta1[1],
+                             pt == 0 ? alpha[0] : alpha[1], adj, GSBLOCK);
+            double val[Q_COUNT * 2];
+            gc_finish_gradient(ml, m.c.acls, m.c.polar, rT, adj, GSBLOCK, val);
+            const bool polar = m.c.polar, assoc = m.c.acls != ASSOC_NONE;
+#pragma unroll 1
+            for (int q = 0; q < Q_COUNT; q++) {
+                const bool need = (q <= Q_Z3) || (q <= Q_MU ? polar : assoc);
+                if (!need) continue;
+                chain(q, 0, wrow * val[2 * q]);
+                chain(q, 1, wrow * val[2 * q + 1]);
+            }
+        } else {
             // zero-tangent dual copy of the bond diameters (their derivative is part (3))
 #pragma unroll 1
             for (int e = 0; e < 2 * GC_MAXE; e++) gbonds[threadIdx.x + e * GSBLOCK] = G(m.c.bond_dab[e * GSBLOCK]);
@@ -264,42 +470,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     if (CH == 1 && j != jm) continue;
-                    const double gq = wrow * val[j];
-#pragma unroll 1
-                    for (int e = 0; e < GC_MAXE; e++) {
-                        const int cnt = row[16 + j * GC_MAXE + e];
-                        if (cnt == 0) continue;
-                        const int a = row[j * GC_MAXE + e];
-                        const double* p = tb.seg + 8 * a;
-                        double* ga = acc + 8 * a;
-                        const double gn = gq * cnt;
-                        if (q == Q_M) {
-                            lds_add(ga + 0, gn);
-                        } else if (q <= Q_Z3) {
-                            double d, ds, de;
-                            diameter_grad(p, rT, d, ds, de);
-                            const int k = q - Q_Z1 + 1;                                   // Z_k = sum n m d^k
-                            const double dk1 = (k == 1) ? 1.0 : (k == 2 ? d : d * d);     // d^(k-1)
-                            lds_add(ga + 0, gn * dk1 * d);
-                            const double t = gn * p[0] * (k * dk1);
-                            lds_add(ga + 1, t * ds);
-                            lds_add(ga + 2, t * de);
-                        } else if (q == Q_S3) {
-                            lds_add(ga + 0, gn * p[1] * p[1] * p[1]);
-                            lds_add(ga + 1, gn * p[0] * 3.0 * p[1] * p[1]);
-                        } else if (q == Q_EK) {
-                            lds_add(ga + 0, gn * p[2]);
-                            lds_add(ga + 2, gn * p[0]);
-                        } else if (q == Q_MU) {
-                            lds_add(ga + 3, gn * 2.0 * p[3]);
-                        } else if (q == Q_SA) {
-                            lds_add(ga + 1, gn * sgn_d(p[4] * p[5]));
-                        } else if (q == Q_EA) {
-                            lds_add(ga + 2, gn * sgn_d(p[4] * p[5]));
-                        } else {
-                            lds_add(ga + (q - Q_KA + 4), gn);  // kappa_ab, epsilon_k_ab, na, nb: plain sums
-                        }
-                    }
+                    chain(q, j, wrow * val[j]);
                 }
             }
         }
@@ -451,7 +622,14 @@ static int launch_gc_gradient(int mode, const GcGradArgs& a, void* stream, const
     const int64_t tiles = (a.n + GSBLOCK - 1) / GSBLOCK;
     const unsigned grid = (unsigned)(tiles < GS_GRID ? tiles : GS_GRID);
     // table + gradient accumulator + per thread: double model 4*MAXE doubles, dual model dab 2*MAXE*(1+CHUNK)
-    const size_t lds = gc_lds_bytes(a.S, GSBLOCK, 4 * GC_MAXE + 2 * GC_MAXE * (1 + 2)) + sizeof(double) * a.S * 8;
+    // (the dual-model area doubles as the lane-strided coefficient-adjoint array of MODE 0: ADJ_SLOTS doubles per thread)
+    constexpr int per_thread = 4 * GC_MAXE + (2 * GC_MAXE * (1 + 2) > ADJ_SLOTS ? 2 * GC_MAXE * (1 + 2) : ADJ_SLOTS);
+    const size_t lds = gc_lds_bytes(a.S, GSBLOCK, per_thread) + sizeof(double) * a.S * 8;
+    if (lds > 64 * 1024) {  // large segment tables: above the default dynamic-LDS limit (the CU has 160 KB)
+        const void* fn = mode == 0 ? reinterpret_cast<const void*>(k_gc_segment_gradient<0>) : reinterpret_cast<const void*>(k_gc_segment_gradient<1>);
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return fail(what, ea);
+    }
     if (mode == 0) hipLaunchKernelGGL(k_gc_segment_gradient<0>, dim3(grid), dim3(GSBLOCK), lds, as_stream(stream), a);
     else hipLaunchKernelGGL(k_gc_segment_gradient<1>, dim3(grid), dim3(GSBLOCK), lds, as_stream(stream), a);
     hipError_t e = hipGetLastError();

@@ -149,6 +149,41 @@ PCS_DEV void gc_mol(GcMol<P, double>& ml, P* bond_dab, double* bond_cnt, int str
     }
 }
 
+// Blocks of gc_finish as functions of their own inputs (the segment-gradient kernel differentiates them one by one).
+// dipoles: molecule-level averages (:66-73), mu2_term = mu2/T (:262)
+template <class P, class Q>
+PCS_DEV void gc_dipole_block(P pj[3][5], P tj[4][4], const Q* M, const Q* S3, const Q* EK, const Q* MU, const P& rT) {
+    P mm[2], sg[2], ek[2], mu2t[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        mm[i] = P(M[i]);
+        sg[i] = P(d_cbrt(S3[i] / M[i]));
+        ek[i] = P(EK[i] / M[i]);
+        mu2t[i] = rT * (MU[i] / M[i] * MU2_UNIT);
+    }
+    dipole_coefficients<P>(pj, tj, mm, sg, ek, mu2t, rT);
+}
+// association contact distances and strengths of class acls (:310-327, :334-356, :384-412)
+template <class P, class Q>
+PCS_DEV void gc_assoc_block(int acls, P* dij, P* S, const Q* sa, const Q* ea, const Q* ka, const Q* eab_, const P& rT) {
+    if (acls == ASSOC_SELF) {
+        Q sg = sa[0] + sa[1], ek = ea[0] + ea[1], kap = ka[0] + ka[1], eab = eab_[0] + eab_[1];
+        P d = sg * (1.0 - 0.12 * d_exp((-3.0 * ek) * rT));
+        dij[0] = 0.5 * d;
+        S[0] = (sg * sg * sg * kap) * (d_exp(eab * rT) - 1.0);
+    } else if (acls != ASSOC_NONE) {
+        P d0 = sa[0] * (1.0 - 0.12 * d_exp((-3.0 * ea[0]) * rT));
+        P d1 = sa[1] * (1.0 - 0.12 * d_exp((-3.0 * ea[1]) * rT));
+        dij[0] = 0.5 * d0;
+        dij[1] = (d0 * d1) * d_recip(d0 + d1);
+        dij[2] = 0.5 * d1;
+        Q ss = sa[0] * sa[1];
+        S[0] = (sa[0] * sa[0] * sa[0] * ka[0]) * (d_exp(eab_[0] * rT) - 1.0);
+        S[1] = (ss * d_sqrt(ss) * d_sqrt(ka[0] * ka[1])) * (d_exp((0.5 * (eab_[0] + eab_[1])) * rT) - 1.0);
+        S[2] = (sa[1] * sa[1] * sa[1] * ka[1]) * (d_exp(eab_[1] * rT) - 1.0);
+    }
+}
+
 // molecule-level sums -> coefficients of gc_a (bond list aside).  Either Q = double or Q = P.
 template <class P, class Q>
 PCS_DEV void gc_finish(GcCoef<P>& c, const GcMol<P, Q>& ml, double phi0, double phi1, const P& rT) {
@@ -172,17 +207,7 @@ PCS_DEV void gc_finish(GcCoef<P>& c, const GcMol<P, Q>& ml, double phi0, double 
     }
     // dipoles: molecule-level averages (:66-73), mu2_term = mu2/T (:262)
     c.polar = (re(ml.MU[0]) > 0.0) || (re(ml.MU[1]) > 0.0);
-    if (c.polar) {
-        P mm[2], sg[2], ek[2], mu2t[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            mm[i] = P(ml.M[i]);
-            sg[i] = P(d_cbrt(ml.S3[i] / ml.M[i]));
-            ek[i] = P(ml.EK[i] / ml.M[i]);
-            mu2t[i] = rT * (ml.MU[i] / ml.M[i] * MU2_UNIT);
-        }
-        dipole_coefficients<P>(c.pj, c.tj, mm, sg, ek, mu2t, rT);
-    }
+    if (c.polar) gc_dipole_block<P, Q>(c.pj, c.tj, ml.M, ml.S3, ml.EK, ml.MU, rT);
     // association (:76-86, :221-251)
     const int associating = (re(ml.ka[0]) * re(ml.eab[0]) != 0.0) + (re(ml.ka[1]) * re(ml.eab[1]) != 0.0);
     const int self_assoc = (re(ml.na[0]) * re(ml.nb[0]) != 0.0) + (re(ml.na[1]) * re(ml.nb[1]) != 0.0);
@@ -196,22 +221,7 @@ PCS_DEV void gc_finish(GcCoef<P>& c, const GcMol<P, Q>& ml, double phi0, double 
         c.nb[i] = P(ml.nb[i]);
         c.isa[i] = sgn_d(re(ml.ka[i]) * re(ml.eab[i]));
     }
-    if (c.acls == ASSOC_SELF) {  // :310-327
-        Q sg = ml.sa[0] + ml.sa[1], ek = ml.ea[0] + ml.ea[1], kap = ml.ka[0] + ml.ka[1], eab = ml.eab[0] + ml.eab[1];
-        P d = sg * (1.0 - 0.12 * d_exp((-3.0 * ek) * rT));
-        c.dij[0] = 0.5 * d;
-        c.S[0] = (sg * sg * sg * kap) * (d_exp(eab * rT) - 1.0);
-    } else if (c.acls != ASSOC_NONE) {  // :334-356, :384-412
-        P d0 = ml.sa[0] * (1.0 - 0.12 * d_exp((-3.0 * ml.ea[0]) * rT));
-        P d1 = ml.sa[1] * (1.0 - 0.12 * d_exp((-3.0 * ml.ea[1]) * rT));
-        c.dij[0] = 0.5 * d0;
-        c.dij[1] = (d0 * d1) * d_recip(d0 + d1);
-        c.dij[2] = 0.5 * d1;
-        Q ss = ml.sa[0] * ml.sa[1];
-        c.S[0] = (ml.sa[0] * ml.sa[0] * ml.sa[0] * ml.ka[0]) * (d_exp(ml.eab[0] * rT) - 1.0);
-        c.S[1] = (ss * d_sqrt(ss) * d_sqrt(ml.ka[0] * ml.ka[1])) * (d_exp((0.5 * (ml.eab[0] + ml.eab[1])) * rT) - 1.0);
-        c.S[2] = (ml.sa[1] * ml.sa[1] * ml.sa[1] * ml.ka[1]) * (d_exp(ml.eab[1] * rT) - 1.0);
-    }
+    gc_assoc_block<P, Q>(c.acls, c.dij, c.S, ml.sa, ml.ea, ml.ka, ml.eab, rT);
 }
 
 // row -> coefficients: T-only work done once per state point (segment diameters, packing sums, dispersion double

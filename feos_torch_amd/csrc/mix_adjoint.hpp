@@ -28,8 +28,8 @@ enum : int {
 // Induced association block of mix_a differentiated forward in its seven inputs (na0, na1, nb0, nb1, Delta_00, Delta_01,
 // Delta_11), first-order tangents over D1s: dn[4] = d a_assoc / d(na0, na1, nb0, nb1), dD[3] = d a_assoc / d Delta_q.  Out of
 // line: its DN<D1s,7> arithmetic needs the register file to itself.
-__device__ __attribute__((noinline)) void induced_assoc_adjoint(const MixCoef<double>& c, D1s r0, D1s r1, D1s D0, D1s D1_, D1s D2, D1s* dn,
-                                                                D1s* dD) {
+__device__ __attribute__((noinline)) void induced_assoc_adjoint(double cna0, double cna1, double cnb0, double cnb1, D1s r0, D1s r1, D1s D0,
+                                                                D1s D1_, D1s D2, D1s* dn, D1s* dD) {
     typedef D1s R;
     const R D[3] = {D0, D1_, D2};
     typedef DN<R, 7> L;
@@ -39,13 +39,13 @@ __device__ __attribute__((noinline)) void induced_assoc_adjoint(const MixCoef<do
 #pragma unroll
     for (int k = 0; k < 7; k++) {
         in[k] = L(0.0);
-        in[k].v = k == 0 ? R(c.na[0]) : k == 1 ? R(c.na[1]) : k == 2 ? R(c.nb[0]) : k == 3 ? R(c.nb[1]) : D[k - 4];
+        in[k].v = k == 0 ? R(cna0) : k == 1 ? R(cna1) : k == 2 ? R(cnb0) : k == 3 ? R(cnb1) : D[k - 4];
         in[k].e[k] = R(1.0);
     }
     const L &na0 = in[0], &na1 = in[1], &nb0 = in[2], &nb1 = in[3];
     const L d00 = in[4] * rl0, d01 = in[5] * rl1, d10 = in[5] * rl0, d11 = in[6] * rl1;
     // real part exactly as mix_a: bracketed Newton from 0.2
-    const double n0 = c.na[0], n1 = c.na[1], m0 = c.nb[0], m1n = c.nb[1];
+    const double n0 = cna0, n1 = cna1, m0 = cnb0, m1n = cnb1;
     const double e00 = re(d00), e01 = re(d01), e10 = re(d10), e11 = re(d11);
     double x = 0.2, lo = 0.0, hi = 2.0;
     for (int it = 0; it < 200; it++) {
@@ -74,16 +74,21 @@ __device__ __attribute__((noinline)) void induced_assoc_adjoint(const MixCoef<do
     dD[2] = aas.e[6];
 }
 
-// (out of line: the evaluation wants the whole register file to itself, like the solvers' phase_eval)
-__device__ __attribute__((noinline)) void mix_a_adjoint(const MixCoef<double>& c, double q0, double q1, double b0, double b1, double alpha,
-                                                        double* out, int stride) {
-    typedef D1s R;
-    const R r0(q0, b0), r1(q1, b1);
+// state shared by the parts of an adjoint evaluation: the density point along its direction, the packing quantities and
+// the running derivatives of a with respect to the packing sums
+struct AdjCtx {
+    D1s r0, r1, r00, r01, r11, zeta2, zeta3, omz, z3m1, z3m2, dz0, dz1, dz2, dz3;
+};
 #define PCS_ADJ(slot, expr)                          \
     {                                                \
         const R g_ = (expr);                         \
         out[(slot) * stride] += alpha * g_.v + g_.d1; \
     }
+// packing sums, hard sphere, dispersion, dipoles: any coefficient struct with m, zk, A, B, polar, pj, tj (MixCoef, GcCoef)
+template <class C>
+PCS_DEV void adjoint_core(const C& c, double q0, double q1, double b0, double b1, double alpha, double* out, int stride, AdjCtx& x) {
+    typedef D1s R;
+    const R r0(q0, b0), r1(q1, b1);
     const R zeta0 = r0 * c.zk[0][0] + r1 * c.zk[0][1];
     const R zeta1 = r0 * c.zk[1][0] + r1 * c.zk[1][1];
     const R zeta2 = r0 * c.zk[2][0] + r1 * c.zk[2][1];
@@ -101,19 +106,6 @@ __device__ __attribute__((noinline)) void mix_a_adjoint(const MixCoef<double>& c
     R dz2 = (3.0 * K) * (zeta1 * z3m1 + (zeta2 * zeta23) * z3m2 + (zeta23 * zeta23) * l13);
     R dz3 = K * (3.0 * ((zeta1 * zeta2) * z3m2) + t3 * (2.0 * ((z3m1 * z3m2) * rz3) - z3m2 * rz3sq) - 2.0 * ((t3 * (rz3sq * rz3)) * l13) -
                  (t3 * rz3sq - zeta0) * z3m1);
-    // hard chain (:63-65): a = -sum r_i mm1_i ln g_i,  g_i = 1/(1-z3) + 1.5 d_i cc + 0.5 d_i^2 cc^2 (1-z3),  cc = z2/(1-z3)^2
-    const R cc = zeta2 * z3m2;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const R& ri = i == 0 ? r0 : r1;
-        const R cd = cc * c.d[i];
-        const R g = z3m1 + 1.5 * cd + 0.5 * ((cd * cd) * omz);
-        const R pre = (ri * c.mm1[i]) * d_recip(g);
-        PCS_ADJ(ADJ_MM1 + i, -(ri * d_log(g)));
-        PCS_ADJ(ADJ_D + i, -(pre * (1.5 * cc + (cd * cc) * omz)));
-        dz2 = dz2 - pre * ((1.5 * c.d[i] + c.d[i] * (cd * omz)) * z3m2);
-        dz3 = dz3 - pre * (z3m2 + 3.0 * (cd * z3m1) + 1.5 * (cd * cd));
-    }
     // dispersion (:69-106): a = -pi [2 rho1mix I1 + rho2mix C1 I2 m_bar]
     const R r00 = r0 * r0, r01 = r0 * r1, r11 = r1 * r1;
     {
@@ -199,19 +191,89 @@ __device__ __attribute__((noinline)) void mix_a_adjoint(const MixCoef<double>& c
         }
         dz3 = dz3 + f2 * phi2d + f3 * phi3d;
     }
-    // association (:118-152).  Delta_q = S_q (1 + k_q (2 k_q + 3)) / (1 - z3),  k_q = dij_q z2/(1 - z3)
-    if (c.acls != ASSOC_NONE) {
-        const R zz = zeta2 * z3m1;
-        const int nq = c.acls == ASSOC_SELF ? 1 : 3;
-        R kq[3], pk[3], D[3], dD[3];
+    x.r0 = r0; x.r1 = r1; x.r00 = r00; x.r01 = r01; x.r11 = r11;
+    x.zeta2 = zeta2; x.zeta3 = zeta3; x.omz = omz; x.z3m1 = z3m1; x.z3m2 = z3m2;
+    x.dz0 = dz0; x.dz1 = dz1; x.dz2 = dz2; x.dz3 = dz3;
+}
+
+// association strengths Delta_q = S_q (1 + k_q (2 k_q + 3))/(1 - z3), k_q = dij_q z2/(1 - z3), q < nq
+struct AdjDelta {
+    D1s kq[3], pk[3], D[3];
+};
+template <class C>
+PCS_DEV void adjoint_delta(const C& c, const AdjCtx& x, int nq, AdjDelta& dl) {
+    typedef D1s R;
+    const R zz = x.zeta2 * x.z3m1;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            if (q < nq) {
-                kq[q] = zz * c.dij[q];
-                pk[q] = kq[q] * (2.0 * kq[q] + 3.0) + 1.0;
-                D[q] = (z3m1 * pk[q]) * c.S[q];
-            }
+    for (int q = 0; q < 3; q++) {
+        if (q < nq) {
+            dl.kq[q] = zz * c.dij[q];
+            dl.pk[q] = dl.kq[q] * (2.0 * dl.kq[q] + 3.0) + 1.0;
+            dl.D[q] = (x.z3m1 * dl.pk[q]) * c.S[q];
         }
+    }
+}
+// from dD[q] = da/dDelta_q to the adjoints of S, dij and the packing sums
+template <class C>
+PCS_DEV void adjoint_delta_chain(const C& c, AdjCtx& x, int nq, const AdjDelta& dl, const D1s* dD, double alpha, double* out, int stride) {
+    typedef D1s R;
+    const R zz = x.zeta2 * x.z3m1;
+    R dzz(0.0);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        if (q < nq) {
+            PCS_ADJ(ADJ_S + q, dD[q] * (x.z3m1 * dl.pk[q]));
+            const R dS = dD[q] * c.S[q];
+            const R dk = dS * (x.z3m1 * (4.0 * dl.kq[q] + 3.0));
+            PCS_ADJ(ADJ_DIJ + q, dk * zz);
+            dzz = dzz + dk * c.dij[q];
+            x.dz3 = x.dz3 + dS * (x.z3m2 * dl.pk[q]);
+        }
+    }
+    x.dz2 = x.dz2 + dzz * x.z3m1;
+    x.dz3 = x.dz3 + dzz * (x.zeta2 * x.z3m2);
+}
+// d/dzk[k][i] = (da/dzeta_k) r_i
+PCS_DEV void adjoint_flush(const AdjCtx& x, double alpha, double* out, int stride) {
+    typedef D1s R;
+    PCS_ADJ(ADJ_ZK + 0, x.dz0 * x.r0);
+    PCS_ADJ(ADJ_ZK + 1, x.dz0 * x.r1);
+    PCS_ADJ(ADJ_ZK + 2, x.dz1 * x.r0);
+    PCS_ADJ(ADJ_ZK + 3, x.dz1 * x.r1);
+    PCS_ADJ(ADJ_ZK + 4, x.dz2 * x.r0);
+    PCS_ADJ(ADJ_ZK + 5, x.dz2 * x.r1);
+    PCS_ADJ(ADJ_ZK + 6, x.dz3 * x.r0);
+    PCS_ADJ(ADJ_ZK + 7, x.dz3 * x.r1);
+}
+
+// (out of line: the evaluation wants the whole register file to itself, like the solvers' phase_eval)
+__device__ __attribute__((noinline)) void mix_a_adjoint(const MixCoef<double>& c, double q0, double q1, double b0, double b1, double alpha,
+                                                        double* out, int stride) {
+    typedef D1s R;
+    AdjCtx x;
+    adjoint_core(c, q0, q1, b0, b1, alpha, out, stride, x);
+    const R &r0 = x.r0, &r1 = x.r1, &zeta2 = x.zeta2, &omz = x.omz, &z3m1 = x.z3m1, &z3m2 = x.z3m2;
+    R &dz2 = x.dz2, &dz3 = x.dz3;
+    // hard chain (:63-65): a = -sum r_i mm1_i ln g_i,  g_i = 1/(1-z3) + 1.5 d_i cc + 0.5 d_i^2 cc^2 (1-z3),  cc = z2/(1-z3)^2
+    const R cc = zeta2 * z3m2;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const R& ri = i == 0 ? r0 : r1;
+        const R cd = cc * c.d[i];
+        const R g = z3m1 + 1.5 * cd + 0.5 * ((cd * cd) * omz);
+        const R pre = (ri * c.mm1[i]) * d_recip(g);
+        PCS_ADJ(ADJ_MM1 + i, -(ri * d_log(g)));
+        PCS_ADJ(ADJ_D + i, -(pre * (1.5 * cc + (cd * cc) * omz)));
+        dz2 = dz2 - pre * ((1.5 * c.d[i] + c.d[i] * (cd * omz)) * z3m2);
+        dz3 = dz3 - pre * (z3m2 + 3.0 * (cd * z3m1) + 1.5 * (cd * cd));
+    }
+    // association (:118-152)
+    if (c.acls != ASSOC_NONE) {
+        const int nq = c.acls == ASSOC_SELF ? 1 : 3;
+        AdjDelta dl;
+        adjoint_delta(c, x, nq, dl);
+        const R* D = dl.D;
+        R dD[3];
         if (c.acls == ASSOC_SELF) {
             const R rhoa = r0 * c.na[0] + r1 * c.na[1], rhob = r0 * c.nb[0] + r1 * c.nb[1];
             const R sa = rhoa * D[0], sb = rhob * D[0];
@@ -240,7 +302,7 @@ __device__ __attribute__((noinline)) void mix_a_adjoint(const MixCoef<double>& c
             // (:341-375): not a stationary point of the energy, so the block is differentiated forward in its seven inputs
             // (na, nb, Delta_00, Delta_01, Delta_11) -- first-order tangents over the D1s arithmetic of this function
             R dn[4];
-            induced_assoc_adjoint(c, r0, r1, D[0], D[1], D[2], dn, dD);
+            induced_assoc_adjoint(c.na[0], c.na[1], c.nb[0], c.nb[1], r0, r1, D[0], D[1], D[2], dn, dD);
             PCS_ADJ(ADJ_NA + 0, dn[0]);
             PCS_ADJ(ADJ_NA + 1, dn[1]);
             PCS_ADJ(ADJ_NB + 0, dn[2]);
@@ -282,31 +344,9 @@ __device__ __attribute__((noinline)) void mix_a_adjoint(const MixCoef<double>& c
             dD[1] = -((A0_ * B1_) * (xa0 * xb1) + (A1_ * B0_) * (xa1 * xb0));
             dD[2] = -((A1_ * B1_) * (xa1 * xb1));
         }
-        R dzz(0.0);
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            if (q < nq) {
-                PCS_ADJ(ADJ_S + q, dD[q] * (z3m1 * pk[q]));
-                const R dS = dD[q] * c.S[q];
-                const R dk = dS * (z3m1 * (4.0 * kq[q] + 3.0));
-                PCS_ADJ(ADJ_DIJ + q, dk * zz);
-                dzz = dzz + dk * c.dij[q];
-                dz3 = dz3 + dS * (z3m2 * pk[q]);
-            }
-        }
-        dz2 = dz2 + dzz * z3m1;
-        dz3 = dz3 + dzz * (zeta2 * z3m2);
+        adjoint_delta_chain(c, x, nq, dl, dD, alpha, out, stride);
     }
-    // packing sums
-    PCS_ADJ(ADJ_ZK + 0, dz0 * r0);
-    PCS_ADJ(ADJ_ZK + 1, dz0 * r1);
-    PCS_ADJ(ADJ_ZK + 2, dz1 * r0);
-    PCS_ADJ(ADJ_ZK + 3, dz1 * r1);
-    PCS_ADJ(ADJ_ZK + 4, dz2 * r0);
-    PCS_ADJ(ADJ_ZK + 5, dz2 * r1);
-    PCS_ADJ(ADJ_ZK + 6, dz3 * r0);
-    PCS_ADJ(ADJ_ZK + 7, dz3 * r1);
-#undef PCS_ADJ
+    adjoint_flush(x, alpha, out, stride);
 }
 
 // S = sum_k adj[k] c_k for a coefficient set with tangents: its tangent part is the parameter derivative
@@ -339,5 +379,7 @@ PCS_DEV G mix_adjoint_contract(const MixCoef<G>& c, Ptr adj, int stride) {
 #undef PCS_AD
     return S;
 }
+
+#undef PCS_ADJ
 
 }  // namespace pcs

@@ -35,3 +35,6 @@ for nm in sys.argv[1:]:
             ms0, _ = t(lambda: native.gc_jacobian(tab, len(ident), rows, phi, T, rho4, False)); ms, jj = t(lambda: native.gc_jacobian(tab, len(ident), rows, phi, T, rho4, False, order=order)); j = jj[0] if isinstance(jj, (tuple, list)) else jj
             out.append(f"jacobian {ms0:.2f} -> ordered {ms:.2f} ms sum {float(j[~r['status']].abs().sum()):.12e}")
     print("  ".join(out))
+    # segment-parameter gradient at the bubble-point densities of the last variant
+    ms, gseg = t(lambda: native.gc_segment_gradient(tab, len(ident), rows, phi, T, rho4, False, order=order))
+    print(f"  {nm} segment gradient {ms:.2f} ms  sum {float(gseg.abs().sum()):.12e}")
