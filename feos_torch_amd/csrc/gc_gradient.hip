@@ -41,7 +41,47 @@ template <int MODE> struct GsChunk { static constexpr int value = MODE == 0 ? 2 
 
 enum : int { Q_M, Q_Z1, Q_Z2, Q_Z3, Q_S3, Q_EK, Q_MU, Q_SA, Q_EA, Q_KA, Q_EAB, Q_NA, Q_NB, Q_COUNT };
 
-__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+// Accumulation into the workgroup's [S,8] gradient table in LDS: ds_add_f64 per contributing lane (PCS_GC_WAVE_ACC = 0).
+// PCS_GC_WAVE_ACC = 1 (experiment, off): the workgroup is ONE wave and with class-ordered rows many of its lanes add to the
+// same table entry at the same time; there the lanes that target the same entry are summed with a DPP butterfly and ONE
+// lane does a plain read-modify-write, once per distinct entry in the wave.  Measured on 1e6 rows: 6.55 ms against 4.71 ms
+// with the atomics -- the waits of this kernel (PMC: 71 % of the wave cycles) are not the LDS atomics.  Either way every
+// lane of the wave reaches the call (on = this lane contributes).
+#ifndef PCS_GC_WAVE_ACC
+#define PCS_GC_WAVE_ACC 0
+#endif
+__device__ __forceinline__ double wave_sum(double x) {
+#define PCS_DPP_STEP(ctrl, rmask)                                                                \
+    {                                                                                            \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, rmask, 0xf, false); \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, rmask, 0xf, false); \
+        x += __hiloint2double(hi, lo);                                                           \
+    }
+    PCS_DPP_STEP(0xB1, 0xf)   // quad_perm [1,0,3,2]
+    PCS_DPP_STEP(0x4E, 0xf)   // quad_perm [2,3,0,1]
+    PCS_DPP_STEP(0x141, 0xf)  // row_half_mirror
+    PCS_DPP_STEP(0x140, 0xf)  // row_mirror: every lane holds its row's sum
+    PCS_DPP_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    PCS_DPP_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+#undef PCS_DPP_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+__device__ __forceinline__ void lds_add(double* p, double v, bool on) {
+#if PCS_GC_WAVE_ACC
+    const unsigned a32 = (unsigned)(uintptr_t)p;
+    unsigned long long todo = __ballot(on);
+    while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned la = (unsigned)__builtin_amdgcn_readlane((int)a32, leader);
+        const bool mine = on && a32 == la;
+        const double tot = wave_sum(mine ? v : 0.0);
+        if ((int)threadIdx.x == leader) *p += tot;
+        todo &= ~__ballot(mine);
+    }
+#else
+    if (on) unsafeAtomicAdd(p, v);
+#endif
+}
 
 // d and its derivatives w.r.t. sigma and epsilon_k of the segment (:118-120)
 __device__ __forceinline__ void diameter_grad(const double* seg, double rT, double& d, double& d_sig, double& d_eps) {
@@ -286,11 +326,14 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
     const int64_t tiles = (n + GSBLOCK - 1) / GSBLOCK;
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        // every lane runs the body (the accumulation below is a wave-level reduction); lanes past the end repeat a valid
+        // row with weight zero
         int64_t i = tile * GSBLOCK + threadIdx.x;
-        if (i >= n) continue;
+        bool live = i < n;
+        if (!live) i = n - 1;
         if (order) {
             i = order[i];
-            if (i < 0 || i >= n) continue;
+            if (i < 0 || i >= n) { live = false; i = 0; }
         }
         const unsigned char* row = rows + (size_t)i * GC_ROW_BYTES;
         const double T = temp[i], ph0 = phi[2 * i], ph1 = phi[2 * i + 1];
@@ -377,44 +420,45 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
         };
         // weight of this row: upstream gradient x (reduced -> Pa); a singular adjoint poisons the result like the
         // per-row NaN of pcs_gc_jacobian
-        const double wrow = MODE == 0 ? (ok ? (gout ? gout[i] : 1.0) * (T * P_UNIT) : nanv) : 1.0;
+        const double wrow = !live ? 0.0 : MODE == 0 ? (ok ? (gout ? gout[i] : 1.0) * (T * P_UNIT) : nanv) : 1.0;
 
         // chain from a molecule-level sum (quantity q of molecule j, gq = weight x d functional / d sum) to the segment
         // parameters of that molecule's entries
-        auto chain = [&](int q, int j, double gq) {
+        auto chain = [&](int q, int j, double gq, bool on_q) {
 #pragma unroll 1
             for (int e = 0; e < GC_MAXE; e++) {
                 const int cnt = row[16 + j * GC_MAXE + e];
-                if (cnt == 0) continue;
+                const bool on = on_q && cnt != 0;
+                if (__ballot(on) == 0ull) continue;
                 const int a = row[j * GC_MAXE + e];
                 const double* p = tb.seg + 8 * a;
                 double* ga = acc + 8 * a;
                 const double gn = gq * cnt;
                 if (q == Q_M) {
-                    lds_add(ga + 0, gn);
+                    lds_add(ga + 0, gn, on);
                 } else if (q <= Q_Z3) {
                     double d, ds, de;
                     diameter_grad(p, rT, d, ds, de);
                     const int k = q - Q_Z1 + 1;                                   // Z_k = sum n m d^k
                     const double dk1 = (k == 1) ? 1.0 : (k == 2 ? d : d * d);     // d^(k-1)
-                    lds_add(ga + 0, gn * dk1 * d);
+                    lds_add(ga + 0, gn * dk1 * d, on);
                     const double t = gn * p[0] * (k * dk1);
-                    lds_add(ga + 1, t * ds);
-                    lds_add(ga + 2, t * de);
+                    lds_add(ga + 1, t * ds, on);
+                    lds_add(ga + 2, t * de, on);
                 } else if (q == Q_S3) {
-                    lds_add(ga + 0, gn * p[1] * p[1] * p[1]);
-                    lds_add(ga + 1, gn * p[0] * 3.0 * p[1] * p[1]);
+                    lds_add(ga + 0, gn * p[1] * p[1] * p[1], on);
+                    lds_add(ga + 1, gn * p[0] * 3.0 * p[1] * p[1], on);
                 } else if (q == Q_EK) {
-                    lds_add(ga + 0, gn * p[2]);
-                    lds_add(ga + 2, gn * p[0]);
+                    lds_add(ga + 0, gn * p[2], on);
+                    lds_add(ga + 2, gn * p[0], on);
                 } else if (q == Q_MU) {
-                    lds_add(ga + 3, gn * 2.0 * p[3]);
+                    lds_add(ga + 3, gn * 2.0 * p[3], on);
                 } else if (q == Q_SA) {
-                    lds_add(ga + 1, gn * sgn_d(p[4] * p[5]));
+                    lds_add(ga + 1, gn * sgn_d(p[4] * p[5]), on);
                 } else if (q == Q_EA) {
-                    lds_add(ga + 2, gn * sgn_d(p[4] * p[5]));
+                    lds_add(ga + 2, gn * sgn_d(p[4] * p[5]), on);
                 } else {
-                    lds_add(ga + (q - Q_KA + 4), gn);  // kappa_ab, epsilon_k_ab, na, nb: plain sums
+                    lds_add(ga + (q - Q_KA + 4), gn, on);  // kappa_ab, epsilon_k_ab, na, nb: plain sums
                 }
             }
         };
@@ -433,10 +477,10 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
             const bool polar = m.c.polar, assoc = m.c.acls != ASSOC_NONE;
 #pragma unroll 1
             for (int q = 0; q < Q_COUNT; q++) {
-                const bool need = (q <= Q_Z3) || (q <= Q_MU ? polar : assoc);
-                if (!need) continue;
-                chain(q, 0, wrow * val[2 * q]);
-                chain(q, 1, wrow * val[2 * q + 1]);
+                const bool need = live && ((q <= Q_Z3) || (q <= Q_MU ? polar : assoc));
+                if (__ballot(need) == 0ull) continue;
+                chain(q, 0, wrow * val[2 * q], need);
+                chain(q, 1, wrow * val[2 * q + 1], need);
             }
         } else {
             // zero-tangent dual copy of the bond diameters (their derivative is part (3))
@@ -465,12 +509,11 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
                         if (jm == 0) val[0] += v; else val[1] += v;
                     }
                 }
-                if (!need) continue;
                 // chain to the segment parameters of molecule j's entries
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     if (CH == 1 && j != jm) continue;
-                    chain(q, j, wrow * val[j]);
+                    chain(q, j, wrow * val[j], need && live);
                 }
             }
         }
@@ -495,6 +538,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
                 const G one(1.0), nul(0.0);
                 R a = gc_a_tangent<G, R>(c, R(q0, one, nul, nul, nul, nul), R(q1, nul, one, nul, nul, nul));
                 const double v = deriv_contract(dw, a, 0);
+                if (!live) continue;
                 if (pass == 0) g9[6] = v;
                 else if (pass == 1) g9[7] = v + dw.x0;
                 else g9[8] = v + dw.x1;
@@ -523,7 +567,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
             pr[pt][0] = r0;
             pr[pt][1] = r1;
         }
-        if (MODE == 1) {
+        if (MODE == 1 && live) {
             double* g9 = A_.jac9 + 9 * i;
 #pragma unroll
             for (int k = 0; k < 3; k++) { g9[k] = gA[k]; g9[3 + k] = gB[k]; }
@@ -541,37 +585,43 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
             for (int pq = 0; pq < 3; pq++) {
                 const int mi = (pq == 2) ? 1 : 0, mj = (pq == 0) ? 0 : 1;
                 const double gs1 = wrow * gA[pq] * cA[pq], gs2 = wrow * gB[pq] * cB[pq];
+                // two sweeps so that each table entry of the row receives ONE accumulated term per parameter (the sums over
+                // the partner entries stay in registers): side 0 = entries of molecule mi (partner mj), side 1 the reverse
 #pragma unroll 1
-                for (int e = 0; e < GC_MAXE; e++) {
-                    const int ne = row[16 + mi * GC_MAXE + e];
-                    if (ne == 0) continue;
-                    const int a = row[mi * GC_MAXE + e];
-                    const double* pa = tb.seg + 8 * a;
-                    const double ma = ne * pa[0];
+                for (int side = 0; side < 2; side++) {
+                    const int mo = side == 0 ? mi : mj, mp = side == 0 ? mj : mi;  // own / partner molecule
 #pragma unroll 1
-                    for (int f = 0; f < GC_MAXE; f++) {
-                        const int nf = row[16 + mj * GC_MAXE + f];
-                        if (nf == 0) continue;
-                        const int b = row[mj * GC_MAXE + f];
-                        const double* pb = tb.seg + 8 * b;
-                        const double mb = nf * pb[0];
-                        double k1 = 1.0;
-                        if (mi != mj) k1 = tb.K[a * tb.S + b];
-                        const double t1 = tb.E1[a * tb.S + b] * k1, t2 = tb.E2[a * tb.S + b] * (k1 * k1);
-                        const double common = gs1 * t1 + gs2 * t2;
-                        lds_add(acc + 8 * a + 0, (ne * mb) * common);
-                        lds_add(acc + 8 * b + 0, (ma * nf) * common);
-                        const double mm = ma * mb;
-                        const double sab = 0.5 * (pa[1] + pb[1]);
-                        const double dsg = mm * common * (1.5 / sab);  // d sigma_ab^3 / d sigma_a = 1.5 sigma_ab^2
-                        lds_add(acc + 8 * a + 1, dsg);
-                        lds_add(acc + 8 * b + 1, dsg);
-                        // E1 = sqrt(eps_a eps_b) sigma_ab^3: d/d eps_a = E1 / (2 eps_a); the square root is not
-                        // differentiable at eps_a = 0 (segment '>C<'): that term is left out (the reference's autograd
-                        // returns NaN for every epsilon_k there).  E2 = eps_a eps_b sigma_ab^3.
-                        const double s3k2 = sab * sab * sab * (k1 * k1);
-                        lds_add(acc + 8 * a + 2, mm * ((pa[2] != 0.0 ? gs1 * t1 * (0.5 / pa[2]) : 0.0) + gs2 * pb[2] * s3k2));
-                        lds_add(acc + 8 * b + 2, mm * ((pb[2] != 0.0 ? gs1 * t1 * (0.5 / pb[2]) : 0.0) + gs2 * pa[2] * s3k2));
+                    for (int e = 0; e < GC_MAXE; e++) {
+                        const int ne = row[16 + mo * GC_MAXE + e];
+                        const bool on = live && ne != 0;
+                        if (__ballot(on) == 0ull) continue;
+                        const int a = row[mo * GC_MAXE + e];
+                        const double* pa = tb.seg + 8 * a;
+                        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma unroll 1
+                        for (int f = 0; f < GC_MAXE; f++) {
+                            const int nf = row[16 + mp * GC_MAXE + f];
+                            if (nf == 0) continue;
+                            const int b = row[mp * GC_MAXE + f];
+                            const double* pb = tb.seg + 8 * b;
+                            const double mb = nf * pb[0];
+                            double k1 = 1.0;
+                            if (mi != mj) k1 = tb.K[a * tb.S + b];  // E1, E2, K are symmetric tables
+                            const double t1 = tb.E1[a * tb.S + b] * k1, t2 = tb.E2[a * tb.S + b] * (k1 * k1);
+                            const double common = gs1 * t1 + gs2 * t2;
+                            g0 += mb * common;
+                            const double sab = 0.5 * (pa[1] + pb[1]);
+                            g1 += mb * common * (1.5 / sab);  // d sigma_ab^3 / d sigma_a = 1.5 sigma_ab^2
+                            // E1 = sqrt(eps_a eps_b) sigma_ab^3: d/d eps_a = E1 / (2 eps_a); the square root is not
+                            // differentiable at eps_a = 0 (segment '>C<'): that term is left out (the reference's autograd
+                            // returns NaN for every epsilon_k there).  E2 = eps_a eps_b sigma_ab^3.
+                            const double s3k2 = sab * sab * sab * (k1 * k1);
+                            g2 += mb * ((pa[2] != 0.0 ? gs1 * t1 * (0.5 / pa[2]) : 0.0) + gs2 * pb[2] * s3k2);
+                        }
+                        const double ma = ne * pa[0];
+                        lds_add(acc + 8 * a + 0, ne * g0, on);
+                        lds_add(acc + 8 * a + 1, ma * g1, on);
+                        lds_add(acc + 8 * a + 2, ma * g2, on);
                     }
                 }
             }
@@ -583,7 +633,8 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
             for (int e = 0; e < GC_MAXE; e++) {
                 const int slot = (mi * GC_MAXE + e) * GSBLOCK;
                 const double cnt = m.c.bond_cnt[slot];
-                if (cnt == 0.0) continue;
+                const bool on = live && cnt != 0.0;
+                if (__ballot(on) == 0ull) continue;
                 const double dab = m.c.bond_dab[slot];
                 double gd = 0.0;
 #pragma unroll
@@ -600,10 +651,10 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
                 diameter_grad(tb.seg + 8 * b, rT, db, dbs, dbe);
                 const double rs = 1.0 / (da + db);
                 const double wa = gd * (db * rs) * (db * rs), wb = gd * (da * rs) * (da * rs);  // d d_ab / d d_a, d d_b
-                lds_add(acc + 8 * a + 1, wa * das);
-                lds_add(acc + 8 * a + 2, wa * dae);
-                lds_add(acc + 8 * b + 1, wb * dbs);
-                lds_add(acc + 8 * b + 2, wb * dbe);
+                lds_add(acc + 8 * a + 1, wa * das, on);
+                lds_add(acc + 8 * a + 2, wa * dae, on);
+                lds_add(acc + 8 * b + 1, wb * dbs, on);
+                lds_add(acc + 8 * b + 2, wb * dbe, on);
             }
         }
     }
