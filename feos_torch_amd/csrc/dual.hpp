@@ -50,6 +50,10 @@ PCS_DEV double d_log(double x) {
     // the mixture / gc solvers detect degenerate states by the IEEE results of the library log: keep them
     // (positive normal and subnormal arguments take the short form; frexp is exact on subnormals)
     if (!__builtin_amdgcn_class(x, 0x180)) r = (x == 0.0) ? -__builtin_inf() : (x > 0.0 ? x : __builtin_nan(""));
+#else
+    // pure-component unit: an iterate that overshoots the packing-fraction pole makes the argument negative; the solvers
+    // recognise such states by a non-finite result (bit test), so the short form must not return a finite number there
+    if (!__builtin_amdgcn_class(x, 0x380)) r = __longlong_as_double(0x7ff8000000000000LL);  // not +normal / +subnormal / +inf
 #endif
     return r;
 }
