@@ -176,8 +176,7 @@ __global__ __launch_bounds__(NBLOCK) void k_mixn_derivatives(const double* __res
     for (int i = 0; i < NC; i++) polar = polar || mu2t[i] != 0.0;
     if (polar) {
         R phi2(0.0), phi3(0.0);
-#pragma unroll
-        for (int i = 0; i < NC; i++) {
+        for (int i = 0; i < NC; i++) {  // (left to the optimizer: with the triplet loop below it is not unrolled for every NC)
             if (mu2t[i] == 0.0) continue;
 #pragma unroll
             for (int j = i; j < NC; j++) {
