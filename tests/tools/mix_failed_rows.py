@@ -23,3 +23,5 @@ pC, rC, code, info = orc.mix_bubble_dew_continuation(P[idx], K[idx], T[idx], X[i
 print("kernel failed", len(idx), "| oracle A (two attempts) also fails", int(sA.sum()), "| continuation solves", int((code == 0).sum()))
 print("rows kernel fails, oracle A solves:", idx[~sA].tolist()[:60])
 print("rows kernel fails, oracle A fails, continuation solves:", idx[sA & (code == 0)].tolist()[:60])
+if len(sys.argv) > 4:  # optional: save the verdicts for an offline look (CPU, oracle only)
+    np.savez(sys.argv[4], idx=idx, oracle_failed=sA, cont_code=code, p_cont=pC, rho_cont=rC)
