@@ -40,6 +40,52 @@ void pure_vle_row(const double* row, double T, F tol, double* rho_v, double* rho
 
 }  // namespace
 
+// pure-component property gradients at fixed densities, F = double (the reference's fp64 autograd) or long double (exact)
+template <class F>
+static void pure_property_grad_impl(int which, const double* params, const double* T, const double* p_pa,
+                                    const double* rho_v, const double* rho_l, int64_t n, double* value, double* grad) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        typedef DualN<F, 10> G;
+        G p[8];
+        for (int k = 0; k < 8; k++) p[k] = G::var((F)params[8 * i + k], k);
+        PureParams<G> q = make_pure_params<G>(p);
+        G Tg = G::var((F)T[i], 8);
+        G r;
+        if (which == 0) {
+            r = vapor_pressure_formula<G>(q, Tg, G((F)rho_v[i]), G((F)rho_l[i]));
+        } else if (which == 1) {
+            // liquid_density_formula needs Dual3<G>; written out here
+            typedef Dual3<G> D;
+            PureParams<D> qd = {D(q.m, G(0.0), G(0.0)), D(q.sigma, G(0.0), G(0.0)), D(q.epsilon_k, G(0.0), G(0.0)),
+                                D(q.mu2, G(0.0), G(0.0)), D(q.kappa_ab, G(0.0), G(0.0)),
+                                D(q.epsilon_k_ab, G(0.0), G(0.0)), D(q.na, G(0.0), G(0.0)), D(q.nb, G(0.0), G(0.0))};
+            G rho = G((F)rho_l[i]);
+            D h = helmholtz_energy(qd, D(Tg, G(0.0), G(0.0)), D::diff(rho));
+            G pg = rho - h.re + rho * h.v1;
+            G dpg = 1.0 + rho * h.v2;
+            G pspec = G::var((F)p_pa[i], 9) / Tg * (1.0 / P_UNIT);
+            r = (rho - (pg - pspec) / dpg) / RHO_UNIT;
+        } else {
+            typedef Dual3<G> D;
+            PureParams<D> qd = {D(q.m, G(0.0), G(0.0)), D(q.sigma, G(0.0), G(0.0)), D(q.epsilon_k, G(0.0), G(0.0)),
+                                D(q.mu2, G(0.0), G(0.0)), D(q.kappa_ab, G(0.0), G(0.0)),
+                                D(q.epsilon_k_ab, G(0.0), G(0.0)), D(q.na, G(0.0), G(0.0)), D(q.nb, G(0.0), G(0.0))};
+            G rl = G((F)rho_l[i]), rv = G((F)rho_v[i]);
+            D h = helmholtz_energy(qd, D(Tg, G(0.0), G(0.0)), D::diff(rl));
+            G p_l = rl - h.re + rl * h.v1;
+            G dp_l = 1.0 + rl * h.v2;
+            G a_l = h.re / rl;
+            G a_v = helmholtz_energy(q, Tg, rv) / rv;
+            G pp = -(a_v - a_l + log(rv / rl)) / (1.0 / rv - 1.0 / rl);
+            r = (rl - (p_l - pp) / dp_l) / RHO_UNIT;
+        }
+        value[i] = (double)r.re;
+        for (int k = 0; k < 10; k++) grad[10 * i + k] = (double)r.eps[k];
+    }
+}
+
+
 extern "C" {
 
 int orc_num_threads() { return omp_get_max_threads(); }
@@ -189,45 +235,12 @@ void orc_pure_equilibrium_liquid_density(const double* params, const double* T, 
 // For which = 1, rho_v is unused and rho_l is the converged density, p_pa the specification.
 void orc_pure_property_grad(int which, const double* params, const double* T, const double* p_pa,
                             const double* rho_v, const double* rho_l, int64_t n, double* value, double* grad) {
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; i++) {
-        typedef DualN<double, 10> G;
-        G p[8];
-        for (int k = 0; k < 8; k++) p[k] = G::var(params[8 * i + k], k);
-        PureParams<G> q = make_pure_params<G>(p);
-        G Tg = G::var(T[i], 8);
-        G r;
-        if (which == 0) {
-            r = vapor_pressure_formula<G>(q, Tg, G(rho_v[i]), G(rho_l[i]));
-        } else if (which == 1) {
-            // liquid_density_formula needs Dual3<G>; written out here
-            typedef Dual3<G> D;
-            PureParams<D> qd = {D(q.m, G(0.0), G(0.0)), D(q.sigma, G(0.0), G(0.0)), D(q.epsilon_k, G(0.0), G(0.0)),
-                                D(q.mu2, G(0.0), G(0.0)), D(q.kappa_ab, G(0.0), G(0.0)),
-                                D(q.epsilon_k_ab, G(0.0), G(0.0)), D(q.na, G(0.0), G(0.0)), D(q.nb, G(0.0), G(0.0))};
-            G rho = G(rho_l[i]);
-            D h = helmholtz_energy(qd, D(Tg, G(0.0), G(0.0)), D::diff(rho));
-            G pg = rho - h.re + rho * h.v1;
-            G dpg = 1.0 + rho * h.v2;
-            G pspec = G::var(p_pa[i], 9) / Tg * (1.0 / P_UNIT);
-            r = (rho - (pg - pspec) / dpg) / RHO_UNIT;
-        } else {
-            typedef Dual3<G> D;
-            PureParams<D> qd = {D(q.m, G(0.0), G(0.0)), D(q.sigma, G(0.0), G(0.0)), D(q.epsilon_k, G(0.0), G(0.0)),
-                                D(q.mu2, G(0.0), G(0.0)), D(q.kappa_ab, G(0.0), G(0.0)),
-                                D(q.epsilon_k_ab, G(0.0), G(0.0)), D(q.na, G(0.0), G(0.0)), D(q.nb, G(0.0), G(0.0))};
-            G rl = G(rho_l[i]), rv = G(rho_v[i]);
-            D h = helmholtz_energy(qd, D(Tg, G(0.0), G(0.0)), D::diff(rl));
-            G p_l = rl - h.re + rl * h.v1;
-            G dp_l = 1.0 + rl * h.v2;
-            G a_l = h.re / rl;
-            G a_v = helmholtz_energy(q, Tg, rv) / rv;
-            G pp = -(a_v - a_l + log(rv / rl)) / (1.0 / rv - 1.0 / rl);
-            r = (rl - (p_l - pp) / dp_l) / RHO_UNIT;
-        }
-        value[i] = r.re;
-        for (int k = 0; k < 10; k++) grad[10 * i + k] = r.eps[k];
-    }
+    pure_property_grad_impl<double>(which, params, T, p_pa, rho_v, rho_l, n, value, grad);
+}
+// the same in long double (with the cancellation-free site fractions of that instantiation): the exact gradient
+void orc_pure_property_grad_ld(int which, const double* params, const double* T, const double* p_pa,
+                               const double* rho_v, const double* rho_l, int64_t n, double* value, double* grad) {
+    pure_property_grad_impl<long double>(which, params, T, p_pa, rho_v, rho_l, n, value, grad);
 }
 
 // The reference's own Dual3 known-answer vectors (tests/test_dual.py:5-24: x = diff(4), y = 5),

@@ -56,6 +56,7 @@ def lib():
         L.orc_pure_liquid_density_root.argtypes = [_f64p, _f64p, _f64p, _i64, _int, _f64p, _u8p]
         L.orc_pure_equilibrium_liquid_density.argtypes = [_f64p, _f64p, _i64, _int, _f64p, _u8p]
         L.orc_pure_property_grad.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _f64p, _f64p]
+        L.orc_pure_property_grad_ld.argtypes = [_int, _f64p, _f64p, _f64p, _f64p, _f64p, _i64, _f64p, _f64p]
         L.orc_mix_derivatives.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _int, _f64p, _f64p, _f64p, _f64p]
         L.orc_mix_helmholtz.argtypes = [_f64p, _f64p, _f64p, _f64p, _i64, _f64p]
         L.orc_mix_bubble_dew.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p, _i64, _int, _int, _f64p, _f64p, _u8p]
@@ -175,16 +176,17 @@ def pure_equilibrium_liquid_density(params, T, prec=1):
     return rho, st.astype(bool)
 
 
-def pure_property_grad(which, params, T, p_pa, rho_v, rho_l):
-    """value[n], grad[n,10] (d/d 8 params, T, p_spec) with densities held fixed."""
+def pure_property_grad(which, params, T, p_pa, rho_v, rho_l, exact=False):
+    """value[n], grad[n,10] (d/d 8 params, T, p_spec) with densities held fixed.  exact=True: long double (the formulas as
+    written cancel in fp64 on strongly associating rows)."""
     params, T = _c(params), _c(T)
     n = T.shape[0]
     p_pa = _c(p_pa if p_pa is not None else np.zeros(n))
     rho_v = _c(rho_v if rho_v is not None else np.zeros(n))
     rho_l = _c(rho_l)
     val, grad = np.empty(n), np.empty((n, 10))
-    lib().orc_pure_property_grad({"vapor_pressure": 0, "liquid_density": 1, "equilibrium_liquid_density": 2}[which],
-                                 params, T, p_pa, rho_v, rho_l, n, val, grad)
+    (lib().orc_pure_property_grad_ld if exact else lib().orc_pure_property_grad)(
+        {"vapor_pressure": 0, "liquid_density": 1, "equilibrium_liquid_density": 2}[which], params, T, p_pa, rho_v, rho_l, n, val, grad)
     return val, grad
 
 

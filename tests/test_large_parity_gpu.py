@@ -142,3 +142,59 @@ def test_gc_bubble_dew_25k(amd, oracle, dew):
     enc = oracle.gc_encode(table, b["segment_lists"], b["bond_lists"], b["kab_list"])
     want, _, st = oracle.gc_bubble_dew(enc, b["phi"], b["T"], b["x"], b["p_init"], dew, prec=1)
     _check(r["p"].cpu().numpy(), r["status"].cpu().numpy().astype(bool), want, st, 10 * SCALE)
+
+
+def test_pure_jacobians_2e5(amd, oracle):
+    """The coefficient-adjoint Jacobian kernels (csrc/pure_jacobian.hpp) on a seeded batch vs the oracle's forward-mode gradient
+    of the reference's formulas at the same densities, in long double (the fp64 evaluation of those formulas is itself off by
+    up to 3e-7 on strongly associating rows): 1e-12 (vapour pressure) / 1e-8 (liquid densities) of the row's largest component
+    on every converged row."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import pure_batch, pure_pressures
+
+    n = 200_000 * SCALE
+    P, T = pure_batch(n, seed=81)
+    psp = pure_pressures(n, seed=82)
+    Pd, Td, pd = _d(P), _d(T), _d(psp)
+    r = native.pure_vle(Pd, Td)
+    ok = ~r["status"].cpu().numpy().astype(bool)
+    rho_vl = r["rho_vl"].cpu().numpy()
+    for prop in ("vapor_pressure", "equilibrium_liquid_density"):
+        J = native.pure_jacobian(prop, Pd, Td, None, r["rho_vl"]).cpu().numpy()
+        _, want = oracle.pure_property_grad(prop, P, T, None, rho_vl[:, 0], rho_vl[:, 1], exact=True)
+        scale = np.abs(want[ok]).max(axis=1, keepdims=True)
+        err = np.abs(J[ok] - want[ok]) / scale
+        print(f"{prop}: rows {ok.sum()} max {err.max():.2e} q99.99 {np.quantile(err.max(axis=1), 0.9999):.2e}")
+        # the two liquid-density properties drop a term proportional to the last Newton step of the solve (csrc/pure_jacobian.hpp)
+        assert err.max() < (1e-12 if prop == "vapor_pressure" else 1e-8), prop
+    r2 = native.pure_liquid_density(Pd, Td, pd)
+    ok = ~r2["status"].cpu().numpy().astype(bool)
+    rho_vl = torch.stack([torch.zeros_like(r2["rho_root"]), r2["rho_root"]], dim=1)
+    J = native.pure_jacobian("liquid_density", Pd, Td, pd, rho_vl).cpu().numpy()
+    _, want = oracle.pure_property_grad("liquid_density", P, T, psp, None, r2["rho_root"].cpu().numpy(), exact=True)
+    scale = np.abs(want[ok]).max(axis=1, keepdims=True)
+    err = np.abs(J[ok] - want[ok]) / scale
+    print(f"liquid_density: rows {ok.sum()} max {err.max():.2e}")
+    assert err.max() < 1e-8
+
+
+@pytest.mark.parametrize("dew", [False, True])
+def test_mix_jacobian_3e4(amd, oracle, dew):
+    """The coefficient-adjoint pressure gradient (csrc/mix_adjoint.hpp) on a seeded batch, every association class, vs the
+    exact (long-double) gradient of the reference's final Newton step at the same densities: 1e-8 of the row's largest
+    component on every converged row."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import mix_batch
+
+    n = 30_000 * SCALE
+    P, K, T, X, PI = mix_batch(n, seed=83)
+    a = [_d(v) for v in (P, K, T, X, PI)]
+    r = native.mix_bubble_dew(*a, dew)
+    ok = ~r["status"].cpu().numpy().astype(bool)
+    rho4 = r["rho4"].cpu().numpy()
+    J = native.mix_jacobian(a[0], a[1], a[2], r["rho4"], dew).cpu().numpy()
+    _, want = oracle.mix_bubble_dew_grad(P[ok], K[ok], T[ok], rho4[ok], dew, exact=True)
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    err = np.abs(J[ok] - want) / scale
+    print(f"{'dew' if dew else 'bubble'} gradient: rows {ok.sum()} max {err.max():.2e} q99.99 {np.quantile(err.max(axis=1), 0.9999):.2e}")
+    assert err.max() < 1e-8

@@ -165,16 +165,18 @@ def test_jacobian_vs_oracle(amd, oracle):
     rho_vl = r["rho_vl"].cpu().numpy()
     for prop in ("vapor_pressure", "equilibrium_liquid_density"):
         J = native.pure_jacobian(prop, Pd, Td, None, r["rho_vl"]).cpu().numpy()
-        _, want = oracle.pure_property_grad(prop, P, T, None, rho_vl[:, 0], rho_vl[:, 1])
+        # exact (long-double) gradient of the reference's formula: its fp64 evaluation is itself off by up to 3e-7 on strongly
+        # associating rows.  The liquid-density properties drop a term proportional to the last Newton step of the solve.
+        _, want = oracle.pure_property_grad(prop, P, T, None, rho_vl[:, 0], rho_vl[:, 1], exact=True)
         scale = np.abs(want[ok]).max(axis=1, keepdims=True)
-        assert np.max(np.abs(J[ok] - want[ok]) / scale) < 1e-7, prop
+        assert np.max(np.abs(J[ok] - want[ok]) / scale) < (1e-12 if prop == "vapor_pressure" else 1e-8), prop
     r2 = native.pure_liquid_density(Pd, Td, pd)
     ok = ~r2["status"].cpu().numpy()
     rho_vl = torch.stack([torch.zeros_like(r2["rho_root"]), r2["rho_root"]], dim=1)
     J = native.pure_jacobian("liquid_density", Pd, Td, pd, rho_vl).cpu().numpy()
-    _, want = oracle.pure_property_grad("liquid_density", P, T, psp, None, r2["rho_root"].cpu().numpy())
+    _, want = oracle.pure_property_grad("liquid_density", P, T, psp, None, r2["rho_root"].cpu().numpy(), exact=True)
     scale = np.abs(want[ok]).max(axis=1, keepdims=True)
-    assert np.max(np.abs(J[ok] - want[ok]) / scale) < 1e-7
+    assert np.max(np.abs(J[ok] - want[ok]) / scale) < 1e-8
 
 
 # ------------------------------------------------------------------------------------------
