@@ -63,8 +63,10 @@ __device__ __forceinline__ void stage_params(const double* __restrict__ params, 
 // K1: pure VLE, fast path.  Rows that need the robust initialisation are appended to
 // retry[1..]; retry[0] is the running count.
 // ------------------------------------------------------------------------------------------
+// waves per SIMD asked of the compiler for the all-fp64 instantiation (p_sat + densities): 210 VGPRs fit two; held to 128
+// (152 spill instructions) four are resident and the kernel is 1.20 -> 0.96 ms per 1e7 rows (three: 1.00 ms)
 #ifndef K1_WAVES
-#define K1_WAVES 2
+#define K1_WAVES 4
 #endif
 #ifndef PCS_LITE_LDS_ROW
 #define PCS_LITE_LDS_ROW 1
@@ -294,10 +296,15 @@ __global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restri
 // ------------------------------------------------------------------------------------------
 // K2: liquid density at (T, p)
 // ------------------------------------------------------------------------------------------
+// liquid-density kernel: 204 VGPRs fit two waves per SIMD; held to 168 (52 spill instructions) three: 1.02 -> 0.89 ms per 1e7
+// rows (four, 128 VGPRs: 1.02 ms)
+#ifndef K2_WAVES
+#define K2_WAVES 3
+#endif
 #ifndef PCS_K2_BUCKET
 #define PCS_K2_BUCKET 1  // A/B 1e7 rows: 1.34 -> 1.22 ms
 #endif
-__global__ __launch_bounds__(BLOCK) void k_pure_liquid_density(const double* __restrict__ params,
+__global__ __launch_bounds__(BLOCK, K2_WAVES) void k_pure_liquid_density(const double* __restrict__ params,
                                                                const double* __restrict__ temp,
                                                                const double* __restrict__ pressure, int64_t n,
                                                                double* __restrict__ rho_out,

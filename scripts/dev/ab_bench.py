@@ -17,9 +17,11 @@ for nm in names:
     libs[nm] = L
 p = torch.empty(n, dtype=torch.float64, device="cuda"); st = torch.empty(n, dtype=torch.uint8, device="cuda")
 ws = torch.empty(n + 64, dtype=torch.int32, device="cuda")
+# PCS_AB_FULL=1: the all-fp64 kernel (densities returned) instead of the pressure-only one
+rho_vl = torch.empty((n, 2), dtype=torch.float64, device="cuda") if os.environ.get("PCS_AB_FULL") else None
 stream = vp(torch.cuda.current_stream().cuda_stream)
 def run(L, retry=False):
-    args = (vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, None, vp(st.data_ptr()), None, vp(ws.data_ptr()), stream)
+    args = (vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, vp(rho_vl.data_ptr()) if rho_vl is not None else None, vp(st.data_ptr()), None, vp(ws.data_ptr()), stream)
     assert L.pcs_pure_vle_fast(*args) == 0
     if retry: assert L.pcs_pure_vle_retry(*args) == 0
 times = {nm: [] for nm in names}; rtimes = {nm: [] for nm in names}
@@ -31,7 +33,7 @@ for rnd in range(12):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e2 = torch.cuda.Event(enable_timing=True)
         e0.record(); run(libs[nm]); e1.record()
-        args = (vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, None, vp(st.data_ptr()), None, vp(ws.data_ptr()), stream)
+        args = (vp(Pd.data_ptr()), vp(Td.data_ptr()), n, vp(p.data_ptr()), None, vp(rho_vl.data_ptr()) if rho_vl is not None else None, vp(st.data_ptr()), None, vp(ws.data_ptr()), stream)
         libs[nm].pcs_pure_vle_retry(*args); e2.record(); torch.cuda.synchronize()
         if rnd >= 2: times[nm].append(e0.elapsed_time(e1)); rtimes[nm].append(e1.elapsed_time(e2))
 base = np.median(times[names[0]])

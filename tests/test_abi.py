@@ -107,9 +107,14 @@ def test_kernel_stack_frames_and_occupancy(hip_lib):
     for which in range(3):
         jac = res[f"void k_pure_jacobian<{which}>"]
         assert jac["occupancy"] >= 2 and jac["scratch"] <= 256, (which, jac)
-    for name, r in res.items():
-        if "k_pure_vle" in name or "k_pure_liquid_density" in name or name == "k_pure_derivatives":
-            assert r["scratch"] == 0, (name, r)
+    # the all-fp64 VLE kernel and the liquid-density kernel trade a small spill frame for one / two more resident waves
+    # (measured faster, csrc/pure_kernels.hip); the others use no stack
+    full = res["void k_pure_vle<false>"]
+    assert full["occupancy"] >= 4 and full["scratch"] <= 320, full
+    k2 = res["k_pure_liquid_density"]
+    assert k2["occupancy"] >= 3 and k2["scratch"] <= 160, k2
+    for name in ("k_pure_vle_fallback", "k_pure_vle_robust", "k_pure_derivatives"):
+        assert res[name]["scratch"] == 0, (name, res[name])
 
 
 def test_row_count_validation_is_host_side():
