@@ -298,6 +298,9 @@ __global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restri
 // ------------------------------------------------------------------------------------------
 // liquid-density kernel: 204 VGPRs fit two waves per SIMD; held to 168 (52 spill instructions) three: 1.02 -> 0.89 ms per 1e7
 // rows (four, 128 VGPRs: 1.02 ms)
+#ifndef K4_WAVES
+#define K4_WAVES 2  // Jacobian kernels: two (256 VGPRs); held to 168 for three they spill inside the DN<9> pass: 0.89 -> 2.24 ms
+#endif
 #ifndef K2_WAVES
 #define K2_WAVES 3
 #endif
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void k_pure_derivatives(const double* __rest
 #define PCS_K4_BUCKET 1
 #endif
 template <int WHICH>
-__global__ __launch_bounds__(BLOCK, 2) void k_pure_jacobian(const double* __restrict__ params,
+__global__ __launch_bounds__(BLOCK, K4_WAVES) void k_pure_jacobian(const double* __restrict__ params,
                                                          const double* __restrict__ temp,
                                                          const double* __restrict__ pressure,
                                                          const double* __restrict__ rho_vl, int64_t n,
