@@ -330,6 +330,14 @@ __global__ __launch_bounds__(256) void k_mix_class_scatter(const double* __restr
 #ifndef PCS_QUEUE_LDS_COEF
 #define PCS_QUEUE_LDS_COEF 0
 #endif
+// PCS_QUEUE_LDS_STATE = 1: the per-lane solver state (BdLane, 47 doubles) of the work-queue kernel lives in LDS (24 KB per
+// wave) instead of AGPRs: 1,613 -> 453 AGPR moves and 4,427 -> 3,155 VALU instructions in the kernel body, bubble 2.87 -> 2.71 ms,
+// dew 6.43 -> 6.25 ms per 1e6 rows, identical results.  With the state out of the registers two waves per SIMD were tried again
+// (PCS_QUEUE_WAVES_PER_SIMD = 2): the model coefficients and the loop's own values then spill (344 scratch instructions) and LDS
+// holds six waves per CU: 3.56 / 9.86 ms.
+#ifndef PCS_QUEUE_LDS_STATE
+#define PCS_QUEUE_LDS_STATE 1
+#endif
 struct alignas(16) MixModelSlot {
     MixModel m;
     double pad[(520 - sizeof(MixModel) % 520) / 8];  // lane stride 520 B = 130 dwords: consecutive lanes two banks apart
@@ -352,7 +360,18 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
     const int total = (int)n;
     int next = 0, end = 0;  // this wave's reserved slice [next, end) of the queue (wave-uniform)
     bool drained = false;   // queue head passed n (wave-uniform)
+#if PCS_QUEUE_LDS_STATE
+    // the solver state of every lane in LDS (padded to an odd number of doubles per lane): nothing of it is live in
+    // registers across the evaluation call, so the kernel fits the 256 registers of two waves per SIMD
+    struct alignas(8) LaneSlot {
+        BdLane<DEW> L;
+        double pad[(sizeof(BdLane<DEW>) / 8) % 2 == 0 ? 1 : 2];
+    };
+    __shared__ LaneSlot lane_slots[64];
+    BdLane<DEW>& L = lane_slots[threadIdx.x].L;
+#else
     BdLane<DEW> L;
+#endif
     L.idle();
 #if PCS_QUEUE_LDS_COEF
     MixModel& m = slots[threadIdx.x].m;
