@@ -16,6 +16,9 @@ constexpr int JAC_DIRS = 10;  // 8 parameters, T, p
 #ifndef PCS_JAC_CHUNK
 #define PCS_JAC_CHUNK 2
 #endif
+#ifndef PCS_JAC_BLOCKS
+#define PCS_JAC_BLOCKS 1  // 0: one DN<9> pass over the whole coefficient set
+#endif
 #ifndef PCS_JAC_ADJOINT
 #define PCS_JAC_ADJOINT 1  // closed-form coefficient adjoints + forward tangents of the coefficients only (0: tangents through everything)
 #endif
@@ -192,6 +195,64 @@ PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv
                 adjoint_axpy(c0, adj, gl, wq * Kp * inv_l, [](const D1s& x) { return x.v; });
             }
         }
+#if PCS_JAC_BLOCKS
+        // the coefficient set block by block, each with just its own inputs seeded (pure_model.hpp): core (m, sigma, eps, T)
+        // DN<4>, dipole polynomials (m, sigma, eps, mu, T) DN<5>, association prefactor (sigma, kappa_ab, eps_ab, T) DN<4>;
+        // the site counts enter directly
+#pragma unroll
+        for (int d = 0; d < 9; d++) g[d] = 0.0;
+        {
+            typedef DN<double, 4> G;
+            G x[4];
+            const double v[4] = {par[0], par[1], par[2], T};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x[k].v = v[k];
+#pragma unroll
+                for (int j = 0; j < 4; j++) x[k].e[j] = (j == k) ? 1.0 : 0.0;
+            }
+            PureCoef<G> c;
+            pure_coef_core(c, x[0], x[1], x[2], d_recip(x[3]));
+            G S = c.m * adj.m + c.mm1 * adj.mm1 + c.ceta * adj.ceta + c.kd1 * adj.kd1 + c.kd2 * adj.kd2;
+#pragma unroll
+            for (int k = 0; k < 7; k++) S = S + c.ai[k] * adj.ai[k] + c.bi[k] * adj.bi[k];
+            g[0] += S.e[0]; g[1] += S.e[1]; g[2] += S.e[2]; g[8] += S.e[3];
+        }
+        if (c0.polar) {
+            typedef DN<double, 5> G;
+            G x[5];
+            const double v[5] = {par[0], par[1], par[2], par[3], T};
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                x[k].v = v[k];
+#pragma unroll
+                for (int j = 0; j < 5; j++) x[k].e[j] = (j == k) ? 1.0 : 0.0;
+            }
+            PureCoef<G> c;
+            pure_coef_dipole(c, x[0], x[1], x[2], x[3], d_recip(x[4]));
+            G S = c.qm * adj.qm;
+#pragma unroll
+            for (int k = 0; k < 5; k++) S = S + c.j1[k] * adj.j1[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) S = S + c.j2[k] * adj.j2[k];
+            g[0] += S.e[0]; g[1] += S.e[1]; g[2] += S.e[2]; g[3] += S.e[3]; g[8] += S.e[4];
+        }
+        if (c0.assoc) {
+            typedef DN<double, 4> G;
+            G x[4];
+            const double v[4] = {par[1], par[4], par[5], T};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x[k].v = v[k];
+#pragma unroll
+                for (int j = 0; j < 4; j++) x[k].e[j] = (j == k) ? 1.0 : 0.0;
+            }
+            const G S = pure_coef_da(x[0], x[1], x[2], d_recip(x[3])) * adj.da;
+            g[1] += S.e[0]; g[4] += S.e[1]; g[5] += S.e[2]; g[8] += S.e[3];
+            g[6] += adj.na;
+            g[7] += adj.nb;
+        }
+#else
         typedef DN<double, 9> G9;
         G9 gp[8], gT;
 #pragma unroll
@@ -218,6 +279,7 @@ PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv
         if (c.assoc) S = S + c.da * adj.da + c.na * adj.na + c.nb * adj.nb;
 #pragma unroll
         for (int d = 0; d < 9; d++) g[d] = S.e[d];
+#endif
         g[8] += gT_explicit;
         g[9] = gP_explicit;
         return;

@@ -33,13 +33,11 @@ struct PureCoef {
 // stage 1.  par = (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb)  (README.md:12)
 // for_gradient keeps terms whose VALUE vanishes but whose parameter derivative does not
 // (kappa_ab = 0 or epsilon_k_ab = 0 with sites present).
-template <class P>
-PCS_DEV void pure_coef(PureCoef<P>& c, const P* par, const P& T, bool for_gradient) {
-    const P& m = par[0];
-    const P& sigma = par[1];
-    const P& eps = par[2];
-    const P& mu = par[3];
-    P rT = d_recip(T);
+// The coefficient set in blocks, each a function of its own few inputs (pure_coef calls them in turn; the Jacobian kernel
+// differentiates them one by one with just those inputs seeded, pure_jacobian.hpp).  C: any struct with the members written.
+// core (m, sigma, eps, 1/T): m, mm1, ceta, ai, bi, kd1, kd2
+template <class C, class P>
+PCS_DEV void pure_coef_core(C& c, const P& m, const P& sigma, const P& eps, const P& rT) {
     P s3 = sigma * sigma * sigma;
     P e = eps * rT;
     P d = sigma * (1.0 - 0.12 * d_exp(-3.0 * e));  // :108
@@ -57,36 +55,52 @@ PCS_DEV void pure_coef(PureCoef<P>& c, const P* par, const P& T, bool for_gradie
     P pref = (-PI) * ((m * m) * (e * s3));  // :142
     c.kd1 = 2.0 * pref;
     c.kd2 = pref * (m * e);  // :141
-
-    // dipole (:145-160).  mu2 e s3 = mu^2 / (m s3 eps) * MU2_UNIT * (eps/T) * s3
-    c.polar = re(mu) != 0.0;
-    if (c.polar) {
-        P mu2t = (mu * mu) * (rm * rT) * MU2_UNIT;
-        bool clamp = re(m) > 2.0;  // :146
-        P md1 = clamp ? P(0.5) : m1;
-        P md2 = clamp ? P(0.0) : md1 * m2;
-        // phi2 = rho^2 (-pi/s3) J1, phi3 = rho^3 (-4/3 pi^2/s3) J2 (:158-159);
-        // dipole = phi2^2 mu2t^2 / (phi2 - phi3 mu2t) = rho^2 mu2t^2 J1'^2 / (J1' - rho J2')
-        // with J1' = (-pi/s3) J1 and J2' = (-4/3 pi^2 mu2t/s3) J2.
-        P rs3 = d_recip(s3);
-        P f2 = (-PI) * rs3;
-        P f3 = (-PI_SQ_43) * (rs3 * mu2t);
+}
+// dipole (m, sigma, eps, mu, 1/T): j1, j2, qm (:145-160).  mu2 e s3 = mu^2 / (m s3 eps) * MU2_UNIT * (eps/T) * s3
+template <class C, class P>
+PCS_DEV void pure_coef_dipole(C& c, const P& m, const P& sigma, const P& eps, const P& mu, const P& rT) {
+    P s3 = sigma * sigma * sigma;
+    P e = eps * rT;
+    P rm = d_recip(m);
+    P m1 = (m - 1.0) * rm;
+    P m2 = (m - 2.0) * rm;
+    P mu2t = (mu * mu) * (rm * rT) * MU2_UNIT;
+    bool clamp = re(m) > 2.0;  // :146
+    P md1 = clamp ? P(0.5) : m1;
+    P md2 = clamp ? P(0.0) : md1 * m2;
+    // phi2 = rho^2 (-pi/s3) J1, phi3 = rho^3 (-4/3 pi^2/s3) J2 (:158-159);
+    // dipole = phi2^2 mu2t^2 / (phi2 - phi3 mu2t) = rho^2 mu2t^2 J1'^2 / (J1' - rho J2')
+    // with J1' = (-pi/s3) J1 and J2' = (-4/3 pi^2 mu2t/s3) J2.
+    P rs3 = d_recip(s3);
+    P f2 = (-PI) * rs3;
+    P f3 = (-PI_SQ_43) * (rs3 * mu2t);
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            P a = AD[i][0] + md1 * AD[i][1] + md2 * AD[i][2];
-            if (i < 3) a = a + (BD[i][0] + md1 * BD[i][1] + md2 * BD[i][2]) * e;
-            c.j1[i] = a * f2;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) c.j2[i] = (CD[i][0] + md1 * CD[i][1] + md2 * CD[i][2]) * f3;
-        c.qm = mu2t * mu2t;
+    for (int i = 0; i < 5; i++) {
+        P a = AD[i][0] + md1 * AD[i][1] + md2 * AD[i][2];
+        if (i < 3) a = a + (BD[i][0] + md1 * BD[i][1] + md2 * BD[i][2]) * e;
+        c.j1[i] = a * f2;
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++) c.j2[i] = (CD[i][0] + md1 * CD[i][1] + md2 * CD[i][2]) * f3;
+    c.qm = mu2t * mu2t;
+}
+// association strength prefactor (sigma, kappa_ab, eps_ab, 1/T) (:163-167)
+template <class P>
+PCS_DEV P pure_coef_da(const P& sigma, const P& kap, const P& eab, const P& rT) {
+    P s3 = sigma * sigma * sigma;
+    return (d_exp(eab * rT) - 1.0) * s3 * kap;
+}
 
-    // association (:163-167)
+template <class P>
+PCS_DEV void pure_coef(PureCoef<P>& c, const P* par, const P& T, bool for_gradient) {
+    P rT = d_recip(T);
+    pure_coef_core(c, par[0], par[1], par[2], rT);
+    c.polar = re(par[3]) != 0.0;
+    if (c.polar) pure_coef_dipole(c, par[0], par[1], par[2], par[3], rT);
     c.na = par[6];
     c.nb = par[7];
     bool sites = (re(par[6]) != 0.0) || (re(par[7]) != 0.0);
-    c.da = (d_exp(par[5] * rT) - 1.0) * s3 * par[4];
+    c.da = pure_coef_da(par[1], par[4], par[5], rT);
     c.assoc = sites && (for_gradient || re(c.da) != 0.0);
 }
 
