@@ -290,3 +290,61 @@ def test_bad_rows_fail_cleanly(amd, dew):
     # the rows with NaN / inf / negative temperature or parameters can never converge
     hopeless = torch.from_numpy(np.isin(np.arange(n), bad[[j for j in range(len(bad)) if j % len(kinds) in (0, 1, 2, 5, 6, 11)]])).cuda()
     assert bool(r["status"][hopeless].all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 1000])
+def test_jacobian_ragged_sizes_are_consistent(amd, n):
+    """pcs_mix_jacobian (coefficient adjoints accumulated lane-strided in LDS, csrc/mix_adjoint.hpp): the gradient of a row
+    must depend neither on the batch size nor on the lane / workgroup the class-ordered schedule hands it to."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import mix_batch
+
+    P, K, T, X, PI = mix_batch(1000, seed=37)
+    a = [_t(v).cuda() for v in (P, K, T, X, PI)]
+    for dew in (False, True):
+        r = native.mix_bubble_dew(*a, dew)
+        rho4 = r["rho4"].clone()
+        rho4[r["status"]] = torch.tensor([1e-6, 1e-6, 5e-3, 5e-3], dtype=torch.float64, device="cuda")
+        full = native.mix_jacobian(a[0], a[1], a[2], rho4, dew)
+        part = native.mix_jacobian(a[0][:n].contiguous(), a[1][:n].contiguous(), a[2][:n].contiguous(), rho4[:n].contiguous(), dew)
+        ok = ~r["status"][:n]
+        assert torch.equal(part[ok], full[:n][ok])
+        assert torch.isfinite(part[ok]).all()
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_of_solve_and_gradient_equals_eager(amd):
+    """pcs_mix_bubble_dew (class sort + work-queue kernel) and pcs_mix_jacobian captured in one hipGraph and replayed behind
+    pending work: bit-identical to the eager results (every operation of both calls is a kernel node)."""
+    from feos_torch_amd import native
+    from feos_torch_amd.synthetic import mix_batch
+
+    n = 40_000
+    P, K, T, X, PI = mix_batch(n, seed=43)
+    dev = torch.device("cuda:0")
+    a = [_t(v).to(dev) for v in (P, K, T, X, PI)]
+    ref = native.mix_bubble_dew(*a, True)
+    refj = native.mix_jacobian(a[0], a[1], a[2], ref["rho4"], True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        w = native.mix_bubble_dew(*a, True)
+        native.mix_jacobian(a[0], a[1], a[2], w["rho4"], True)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        got = native.mix_bubble_dew(*a, True)
+        gotj = native.mix_jacobian(a[0], a[1], a[2], got["rho4"], True)
+    for rep in range(2):
+        got["p"].fill_(float("nan"))
+        gotj.fill_(float("nan"))
+        for _ in range(3):  # pending work ahead of the replay
+            native.mix_bubble_dew(*a, False)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got["status"], ref["status"])
+        ok = ~ref["status"]
+        assert torch.equal(got["p"][ok], ref["p"][ok]) and torch.equal(got["rho4"][ok], ref["rho4"][ok])
+        assert torch.equal(gotj[ok], refj[ok])
