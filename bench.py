@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=10_000_000, help="state points per GPU per step (weak) / global batch (strong)")
     ap.add_argument("--chunks", type=int, default=4, help="sub-batches per step of the all-gather legs (gather/solve overlap)")
     ap.add_argument("--no-extra", action="store_true", help="headline leg only (no all-gather / strong / variants legs)")
