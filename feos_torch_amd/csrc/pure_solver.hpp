@@ -271,7 +271,7 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
 // takes dp/drho for its Newton steps and for the second-order term of p* from the fp32 pass -- the Jacobian only
 // steers the step (error ~1e-3 of a ~1e-6 step); the residuals and p* are fp64.  Lanes without a usable fp32
 // result return ST_FALLBACK (the all-fp64 path runs on them in a separate small kernel, which keeps this one at
-// 162 VGPRs), lanes that fail afterwards ST_RETRY (robust pass).
+// 122 VGPRs / four waves per SIMD), lanes that fail afterwards ST_RETRY (robust pass).
 // vle_fast_lite = fp32 pre-solve (pure_f32.hpp) + vle_lite_finish; k_pure_vle<true> runs the two parts itself with the
 // block-level straggler exchange in between.
 PCS_DEV int vle_lite_finish(const double* par, double T, bool warm, double rl, double rv, float dpl32, float dpv32,
