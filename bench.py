@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000, help="state points per GPU per step (weak) / global batch (strong)")
     ap.add_argument("--chunks", type=int, default=4, help="sub-batches per step of the all-gather legs (gather/solve overlap)")
     ap.add_argument("--no-extra", action="store_true", help="headline leg only (no all-gather / strong / variants legs)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="--gpus 1 only: initialise RCCL at world size 1 and run the chunk-overlapped all-gather leg on it "
+                         "(proves the backend, the stream hand-off and the message-size logic; no scaling number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40_000_000, help="upper bound on the rows of the CPU baseline sample")
     return ap.parse_args()
@@ -80,6 +83,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args)  # before anything touches the GPU
+    if args.force_gather and args.gpus == 1:
+        os.environ["PCS_FORCE_DIST"] = "1"  # init_from_env then creates the (RCCL) process group at world size 1
+        os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
 
     import numpy as np
     import torch
@@ -99,8 +105,10 @@ def main():
     Pd = torch.from_numpy(P).to(device)
     Td = torch.from_numpy(T).to(device)
 
+    grouped = dist.is_initialized()  # world > 1, or world 1 with --force-gather
+
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -150,6 +158,7 @@ def main():
             mx_t = torch.tensor([mx], dtype=torch.int64, device=device)
             dist.all_reduce(mx_t, op=dist.ReduceOp.MAX)
             mx = int(mx_t.item())
+            assert mx >= max(p.n for p in plans)
             send_p = [torch.zeros(mx, dtype=torch.float64, device=device) for _ in range(nchunk)]
             send_s = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(nchunk)]
             g_p = [torch.empty(world * mx, dtype=torch.float64, device=device) for _ in range(nchunk)]
@@ -193,6 +202,15 @@ def main():
         del Ps, Ts
 
     # ---- variants of the same batch on one GPU ---------------------------------------------------
+    if world == 1 and grouped:
+        t_g = sharded_leg(Pd, Td, True)
+        extra["allgather_world1"] = {
+            "backend": dist.get_backend(), "value": rows * steps / t_g, "unit": "solves/s", "ms_per_step": t_g / steps * 1e3,
+            "chunks": args.chunks,
+            "note": "--force-gather: the all-gather leg of the N > 1 runs executed on RCCL at world size 1 (kernels write into "
+                    "the send buffers, ncclAllGather per chunk on RCCL's stream overlapped with the next chunk's solve). Proves "
+                    "the backend path only; multi-GPU scaling is UNMEASURED on this pool (one GPU per box).",
+        }
     if world == 1 and not args.no_extra:
         variants = {}
         full = native.PureVlePlan(rows, device, want_rho_vl=True)  # all-fp64 kernel k_pure_vle<false>, returns the densities
@@ -261,12 +279,14 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_pure_vle<pressure-only> (+ k_pure_vle_fallback on the 0.04 % rows without an fp32 pre-solve)",
+                "kernel": "k_pure_vle<pressure-only> (+ the launch of k_pure_vle_fallback for rows without an fp32 pre-solve: "
+                          f"{fallback_rows} on this batch)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of the committed profile, not this run)",
                 "bytes_per_solve": BYTES_PER_SOLVE,
                 "rows_per_launch": rows,
                 "kernel_ms": kern_ms,
@@ -275,6 +295,8 @@ def main():
                 # (counted wave-instructions x issue cycles of the class) / (SIMD-cycles of the launch), a number <= 1
                 # (scripts/summarise_profile.py: PMC instruction count split by the static fp32 / fp64 / transcendental mix)
                 "valu": None if not valu else {
+                    "source": f"profiles/pmc_traffic.json (tag {pmc.get('tag')}: counters and issue costs of the committed "
+                              "profile; only kernel_ms / achieved are measured in this run)",
                     "wave_instr_per_launch": valu,
                     "instr_per_solve": valu * 64.0 / rows,
                     "achieved_gwaveinstr_s": valu / (kern_ms * 1e-3) / 1e9,
@@ -282,16 +304,16 @@ def main():
                     "issue_cycles_per_launch": pmc.get("valu_issue_cycles_per_launch"),
                     "simd_cycles_per_launch": pmc.get("simd_cycles_per_launch"),
                     "mix": pmc.get("valu_mix"),
-                    "valu_busy_pmc": pmc.get("valu_busy"),
                 },
             },
         }
         line.update(extra)
         if not args.no_cpu_baseline and world == 1:
             # OpenMP threads = CPUs this process may use (affinity mask capped by the cgroup quota)
-            from oracle import pyoracle as _o
-            os.environ.setdefault("OMP_NUM_THREADS", str(_o.usable_cpus()))
             from oracle import pyoracle as orc
+
+            os.environ.setdefault("OMP_NUM_THREADS", str(orc.usable_cpus()))
+            orc.use_fast_build()  # the performance build of the same sources (-O3 -march=native), compiled on this host
 
             orc.pure_vapor_pressure(P[:1000], T[:1000], prec=0)  # load + warm
             # size the sample for ~10 s of wall time on this host (bounded by --cpu-sample and the batch)
@@ -307,12 +329,13 @@ def main():
                 "unit": "solves/s",
                 "cores": orc.num_threads(),
                 "kind": "port",
-                "sample": f"first {ns} rows of the same batch, fp64, OpenMP over rows; own CPU restatement "
-                          f"(oracle/), the reference's Rust/feos path is not buildable here",
+                "sample": f"first {ns} rows of the same batch, fp64 (prec=0), OpenMP over rows; own CPU restatement "
+                          f"(oracle/) built with {orc.FAST_FLAGS} on this host; the reference's Rust/feos path is not "
+                          "buildable here",
                 "seconds": ct,
             }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,6 +24,11 @@ SIGNATURES = {
     "pcs_last_error": (ctypes.c_char_p, []),
     "pcs_workspace_bytes": (_i64, [_i64]),
     "pcs_pure_vle": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcs_pure_vapor_pressure": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "pcs_compact_workspace_bytes": (_i64, [_i64]),
+    "pcs_compact_plan": (_int, [_vp, _i64, _vp, _vp]),
+    "pcs_compact_rows": (_int, [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp]),
+    "pcs_expand_rows": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "pcs_pure_vle_fast": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_pure_vle_retry": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_pure_liquid_density": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpcsaft_hip.so")
-SOURCES = ["pure_kernels.hip", "pure_robust.hip", "mix_kernels.hip", "mixn_kernels.hip", "gc_kernels.hip", "gc_gradient.hip"]
+SOURCES = ["pure_kernels.hip", "pure_robust.hip", "compact_kernels.hip", "mix_kernels.hip", "mixn_kernels.hip", "gc_kernels.hip", "gc_gradient.hip"]
 # -fno-honor-nans/-infinities/-signed-zeros: lets the compiler fold the structural zeros of the dual
 # numbers (0 * x, x + 0); every NaN/inf test in the kernels is a bit test (is_finite_bits), so the
 # failure detection does not depend on IEEE comparison semantics.  Measured on k_pure_vle: x1.065,

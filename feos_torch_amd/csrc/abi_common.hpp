@@ -24,11 +24,15 @@ inline int check_n(int64_t n) {
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Device-side counters (retry-list count, work-queue control block) are zeroed by a KERNEL on the call's stream, not by
-// hipMemsetAsync: every operation of a call is then a kernel node of a hipGraph capture.  Established in round 2 with one
-// A/B run (profiles/r02_capture_ab.log): a capture of pcs_pure_vle replayed behind pending launches is bit-identical to the
-// eager call 3/3 times with this reset, while the same library with the hipMemsetAsync reset of round 1 ended its second
-// replay in a GPU memory access fault -- although every list consumer bounds count and entries by n, i.e. the fault is in
-// the replayed memset node itself, not in a kernel reading a stale list.
+// hipMemsetAsync: every operation of a call is then a kernel node of a hipGraph capture.  What round 2's one A/B run shows
+// (profiles/r02_capture_ab.log, scripts/dev/capture_ab.py plants a stale count of 0x7FFFFFF0 before every replay): with this
+// reset a capture of pcs_pure_vle replayed behind pending launches is bit-identical to the eager call 3/3 times; with the
+// hipMemsetAsync reset of round 1 the second replay ended in a GPU memory access fault.  The log does not say which access
+// faulted.  The reading that fits the code: the replayed memset was not reliably ordered before / visible to the first
+// kernel, and the list PRODUCERS of that build appended without a bound (retry[1 + atomicAdd(&retry[0], 1)] = i), i.e. ~8 GB
+// past the workspace on the planted count.  Since round 3 every producer bounds its slot by n (pure_kernels.hip,
+// mix_kernels.hip, gc_kernels.hip) like the consumers always did, so a stale or foreign counter can no longer send a store
+// out of the list whatever resets it.
 template <int DUMMY = 0>
 __global__ void k_zero_ints(int32_t* __restrict__ p, int count) {
     for (int k = threadIdx.x; k < count; k += blockDim.x) p[k] = 0;

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
 #endif
         if (fast && rc != BD_OK) {  // cap hit or failed: the second pass decides
             status[i] = 1;  // provisional
-            retry[1 + atomicAdd(&retry[0], 1)] = (int32_t)i;
+            const int slot = atomicAdd(&retry[0], 1);
+            if (slot >= 0 && slot < n) retry[1 + slot] = (int32_t)i;  // bounded append (see pure_kernels.hip)
         } else {
             gc_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
         }

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
 #endif
     if (rc == BD_CAP) {
         status[i] = 1;  // provisional
-        retry[1 + atomicAdd(&retry[0], 1)] = (int32_t)i;
+        const int slot = atomicAdd(&retry[0], 1);
+        if (slot >= 0 && slot < n) retry[1 + slot] = (int32_t)i;  // bounded append (see pure_kernels.hip)
         return;
     }
     mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);

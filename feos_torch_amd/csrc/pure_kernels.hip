@@ -251,8 +251,9 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
         status[i] = 0;
     } else {
         status[i] = 1;  // provisional; a later pass overwrites it
-        int slot = atomicAdd(&retry[0], 1);
-        retry[1 + slot] = (int32_t)((uint32_t)i | (st == ST_FALLBACK ? 0x80000000u : 0u));  // n < 2^31 checked on the host
+        const int slot = atomicAdd(&retry[0], 1);
+        // bounded append: a counter that was not reset (stale / foreign workspace) must not send the store out of the list
+        if (slot >= 0 && slot < n) retry[1 + slot] = (int32_t)((uint32_t)i | (st == ST_FALLBACK ? 0x80000000u : 0u));  // n < 2^31 checked on the host
     }
 }
 
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(BLOCK) void k_pure_derivatives_vjp(const double* __
 
 extern "C" {
 
-int pcs_abi_version(void) { return 102; }  // 102: pcs_gc_segment_gradient, pcs_*_derivatives_vjp
+int pcs_abi_version(void) { return 103; }  // 103: pcs_pure_vapor_pressure, pcs_compact_* / pcs_expand_rows
 
 const char* pcs_last_error(void) { return g_err; }
 
@@ -490,7 +491,8 @@ int64_t pcs_workspace_bytes(int64_t n) { return (int64_t)sizeof(int32_t) * (n + 
 
 // stage 1: zero the retry counter and run the fast kernel over all rows
 static int launch_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
-                           double* rho_vl, uint8_t* status, int32_t* iters, int32_t* retry, hipStream_t s) {
+                           double* rho_vl, uint8_t* status, int32_t* iters, int32_t* retry, hipStream_t s,
+                           bool force_lite = false) {
     if (int ez = zero_ints(retry, 1, s)) return ez;
     hipError_t e;
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
@@ -498,7 +500,9 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
     // main kernel (lean: rows without an fp32 pre-solve go to the list with bit 31 set) + all-fp64 fallback kernel.
     // LITE only for the pressure-only call: its densities are converged to ~1e-9 (enough for p*, whose error is of
     // second order in them), while rho_eq and the Jacobian kernels (rho_vl) want the ~1e-12 of the D2 finish.
-    if (!rho_eq && !rho_vl)
+    // (pcs_pure_vapor_pressure forces LITE and hands out those ~1e-9 densities: the property then has the same bits
+    // whether or not its caller also wants the Jacobian.)
+    if (!rho_eq && (!rho_vl || force_lite))
         hipLaunchKernelGGL(k_pure_vle<true>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                            iters, retry);
     else
@@ -532,6 +536,16 @@ int pcs_pure_vle(const double* params, const double* temp, int64_t n, double* p_
     int32_t* retry = static_cast<int32_t*>(workspace);
     if (int e = launch_vle_fast(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, as_stream(stream))) return e;
     return launch_vle_retry(params, temp, p_sat, rho_eq, rho_vl, status, iters, retry, n, as_stream(stream));
+}
+
+int pcs_pure_vapor_pressure(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_vl,
+                            uint8_t* status, void* workspace, void* stream) {
+    g_err[0] = 0;
+    if (int e = vle_args_ok(params, temp, n, status, workspace)) return e;
+    if (n == 0) return 0;
+    int32_t* retry = static_cast<int32_t*>(workspace);
+    if (int e = launch_vle_fast(params, temp, n, p_sat, nullptr, rho_vl, status, nullptr, retry, as_stream(stream), true)) return e;
+    return launch_vle_retry(params, temp, p_sat, nullptr, rho_vl, status, nullptr, retry, n, as_stream(stream));
 }
 
 int pcs_pure_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,

@@ -30,9 +30,13 @@ def init_from_env():
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    # PCS_FORCE_DIST=1: initialise the process group at world size 1 too, so that the collectives below really run on the
+    # backend (RCCL on a one-GPU box: bench.py --force-gather, tests/test_rccl_gpu.py)
+    if (world > 1 or os.environ.get("PCS_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # ROCm on these hosts only supports dmabuf IPC handles: with the legacy mode RCCL's (and torch's) cross-process
+        # buffer registration fails with `hipIpcGetMemHandle: invalid argument`
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("PCS_DIST_BACKEND", "nccl" if use_cuda else "gloo")
         if backend == "nccl":
@@ -58,11 +62,12 @@ def all_gather_flat(recv, send, group=None, async_op=False):
     return dist.all_gather(list(recv.view(world, -1).unbind(0)), send, group=group, async_op=async_op)
 
 
-def gather_rows(local, n_total, group=None):
+def gather_rows(local, n_total, group=None, force=False):
     """All-gather 1-D (or [rows, k]) shards that were cut with shard_bounds() back into the
     full-length tensor, on every rank.  Shards are padded to the largest shard so the
-    collective has a static message size."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    collective has a static message size.  At world size 1 the shard is the result and no
+    collective runs unless `force` (exercises the backend on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     sizes = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
@@ -93,10 +98,10 @@ def _hip_vapor_pressure(params, temperature):
     return r["p_sat"], r["status"]
 
 
-def sharded_vapor_pressure(params, temperature, compute=None, group=None):
+def sharded_vapor_pressure(params, temperature, compute=None, group=None, force_collective=False):
     """Vapour pressures of the FULL batch (same `params` [n,8] / `temperature` [n] on every
     rank): each rank solves its contiguous shard, then one all-gather.  Returns dense
-    (p_sat [n], status [n] bool) on every rank."""
+    (p_sat [n], status [n] bool) on every rank.  force_collective: run the all-gather at world size 1 too."""
     compute = compute or _hip_vapor_pressure
     n = temperature.shape[0]
     if dist.is_available() and dist.is_initialized():
@@ -105,8 +110,8 @@ def sharded_vapor_pressure(params, temperature, compute=None, group=None):
         rank, world = 0, 1
     lo, hi = shard_bounds(n, rank, world)
     p_loc, st_loc = compute(params[lo:hi], temperature[lo:hi])
-    p = gather_rows(p_loc, n, group)
-    st = gather_rows(st_loc.to(torch.uint8), n, group).bool()
+    p = gather_rows(p_loc, n, group, force_collective)
+    st = gather_rows(st_loc.view(torch.uint8) if st_loc.dtype == torch.bool else st_loc, n, group, force_collective).bool()
     return p, st
 
 

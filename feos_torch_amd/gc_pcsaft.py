@@ -166,8 +166,12 @@ class _GcDerivatives(torch.autograd.Function):
 
 
 class _GcBubbleDew(torch.autograd.Function):
+    """value[n_ok], nans[n].  Dense solve, one compaction plan (its 4-byte row count is the call's only host synchronisation),
+    single-kernel gathers only when rows were dropped (native.Compaction; the reference drops them inside the native call,
+    src/gc_pcsaft.rs:103-171)."""
+
     @staticmethod
-    def forward(ctx, dew, model, kab, phi, temperature, molefracs, pressure, *segment_parameters):
+    def forward(ctx, dew, model, kab, phi, temperature, molefracs, pressure, box, *segment_parameters):
         dev = model.device
         table = build_table(model.seg.to(dev), kab.detach().to(dev, torch.float64))
         ph = native._prep(phi, dev, (2,))
@@ -175,29 +179,29 @@ class _GcBubbleDew(torch.autograd.Function):
         r = native.gc_bubble_dew(table, model.S, model.rows, ph, T, native._prep(molefracs, dev),
                                  native._prep(pressure, dev), dew, order=model._class_order(table))
         nans = r["status"]
-        all_ok = not bool(nans.any())  # every row converged: slices instead of boolean gathers
-        ok = slice(None) if all_ok else ~nans
-        value = r["p"][ok]
+        comp = native.Compaction(nans)
+        box.append(comp)
+        value = comp.gather(r["p"])
         needs = [ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]]
-        seg_needs = list(ctx.needs_input_grad[7:])
+        seg_needs = list(ctx.needs_input_grad[8:])
+        ctx.saved = False
         if any(needs) or any(seg_needs):
-            rows_ok = model.rows[ok]
+            rows_ok, ph_ok, T_ok, rho4_ok = comp.gather(model.rows), comp.gather(ph), comp.gather(T), comp.gather(r["rho4"])
             # the class order belongs to the uncompacted rows: used when every row converged
-            order = model._class_order(table) if all_ok else None
+            order = model._class_order(table) if comp.all_ok else None
             if any(needs):
-                jac, agg = native.gc_jacobian(table, model.S, rows_ok, ph[ok], T[ok], r["rho4"][ok], dew, order=order)
+                jac, agg = native.gc_jacobian(table, model.S, rows_ok, ph_ok, T_ok, rho4_ok, dew, order=order)
             else:
                 jac = agg = T.new_empty(0)
-            ctx.save_for_backward(jac, agg, nans.new_empty(0) if all_ok else ok, rows_ok, ph[ok], T[ok], table,
-                                  r["rho4"][ok] if any(seg_needs) else T.new_empty(0),
+            ctx.save_for_backward(jac, agg, rows_ok, ph_ok, T_ok, table, rho4_ok if any(seg_needs) else T.new_empty(0),
                                   order if (order is not None and any(seg_needs)) else nans.new_empty(0))
-        ctx.all_ok = all_ok
+            ctx.comp = comp
+            ctx.saved = True
         ctx.needs = needs
         ctx.seg_needs = seg_needs
         ctx.dew = bool(dew)
         ctx.seg_devs = [p.device if isinstance(p, torch.Tensor) else None for p in segment_parameters]
         ctx.S = model.S
-        ctx.n = T.shape[0]
         ctx.devs = (kab.device, phi.device, temperature.device)
         out_device = phi.device
         nans = nans.to(out_device)
@@ -206,30 +210,27 @@ class _GcBubbleDew(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_value, _g):
-        jac, agg, ok, rows, ph, T, table, rho4, order = ctx.saved_tensors
-        if ctx.all_ok:
-            ok = slice(None)
-        S, n = ctx.S, ctx.n
-        g = g_value.to(jac.device)
+        nseg = len(ctx.seg_needs)
+        if not ctx.saved:  # nothing the pressure depends on required a gradient
+            return (None,) * (8 + nseg)
+        jac, agg, rows, ph, T, table, rho4, order = ctx.saved_tensors
+        comp, S = ctx.comp, ctx.S
+        g = g_value.to(table.device).contiguous()
         gk = gphi = gT = None
         if ctx.needs[0]:
             gk = _kab_gradient(table, S, rows, ph, T, g * jac[:, 1], g * jac[:, 4]).to(ctx.devs[0])
         if ctx.needs[1]:
-            gphi = torch.zeros((n, 2), dtype=torch.float64, device=jac.device)
-            gphi[ok] = g[:, None] * _phi_gradient(jac, agg, ph)
-            gphi = gphi.to(ctx.devs[1])
+            gphi = comp.expand(_phi_gradient(jac, agg, ph), g).to(ctx.devs[1])
         if ctx.needs[2]:
-            gT = torch.zeros(n, dtype=torch.float64, device=jac.device)
-            gT[ok] = g * jac[:, 6]
-            gT = gT.to(ctx.devs[2])
-        gseg = [None] * len(ctx.seg_needs)
+            gT = comp.expand(jac, g, 6, 1).view(comp.n).to(ctx.devs[2])
+        gseg = [None] * nseg
         if any(ctx.seg_needs):
             # the whole table in one kernel: sum_i g_i dp_i/d seg[S,8] (the segment-parameter gradient is lazy: it needs
             # the upstream gradient, so unlike the per-row Jacobians above it runs here, not in forward)
             G = native.gc_segment_gradient(table, S, rows, ph, T, rho4, ctx.dew, gout=g,
                                            order=order if order.numel() == rows.shape[0] else None)
             gseg = [G[:, k].to(ctx.seg_devs[k]) if need else None for k, need in enumerate(ctx.seg_needs)]
-        return (None, None, gk, gphi, gT, None, None, *gseg)
+        return (None, None, gk, gphi, gT, None, None, None, *gseg)
 
 
 class GcPcSaftMix:
@@ -244,7 +245,7 @@ class GcPcSaftMix:
         self.S = len(self.segment_identifier)
         if self.S > 32:
             raise ValueError("at most 32 segment types per table")
-        self.device = native._dev()
+        self.device = _device_of(phi, *parameter)
         # the caller's tensors stay attached to the model: they are inputs of the autograd Function of every property
         self._segment_parameters = tuple(p if isinstance(p, torch.Tensor) else torch.as_tensor(p, dtype=torch.float64)
                                          for p in parameter)
@@ -287,16 +288,18 @@ class GcPcSaftMix:
 
     def bubble_point(self, temperature, liquid_molefracs, pressure):
         """(p [Pa], nans) (:470-490)."""
-        value, nans = _GcBubbleDew.apply(False, self, self.kab, self.phi, temperature, liquid_molefracs, pressure,
-                                         *self._segment_parameters)
-        self.reduce(nans)
-        return value, nans
+        return self._bubble_dew(False, temperature, liquid_molefracs, pressure)
 
     def dew_point(self, temperature, vapor_molefracs, pressure):
         """(p [Pa], nans) (:492-512)."""
-        value, nans = _GcBubbleDew.apply(True, self, self.kab, self.phi, temperature, vapor_molefracs, pressure,
+        return self._bubble_dew(True, temperature, vapor_molefracs, pressure)
+
+    def _bubble_dew(self, dew, temperature, molefracs, pressure):
+        box = []
+        # mole fractions and initial pressure do not enter the reference's final formula (:483-490): no gradient flows to them
+        value, nans = _GcBubbleDew.apply(dew, self, self.kab, self.phi, temperature, _detached(molefracs), _detached(pressure), box,
                                          *self._segment_parameters)
-        self.reduce(nans)
+        self._reduce(box[0])
         return value, nans
 
     def _class_order(self, table):
@@ -306,13 +309,29 @@ class GcPcSaftMix:
             self._order = native.gc_class_order(table, self.S, self.rows)
         return self._order
 
+    def _reduce(self, comp):
+        if comp.all_ok:
+            return
+        self.rows = comp.gather(self.rows)
+        self.phi = native.compact_rows(comp, self.phi)
+        self._order = None
+
     def reduce(self, nans):
         """Drop failed rows from the model (:514-528)."""
-        if not bool(nans.any()):
-            return
-        self.rows = self.rows[~nans.to(self.rows.device)]
-        self.phi = self.phi[~nans.to(self.phi.device)]
-        self._order = None
+        self._reduce(native.Compaction(nans.to(self.device)))
+
+
+def _device_of(*tensors):
+    """The GPU a gc model computes on: the device of the first CUDA tensor among its inputs (phi, segment parameters), else the
+    current GPU -- not a device pinned at import or construction time of some other model."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    return native._dev()
+
+
+def _detached(x):
+    return x.detach() if isinstance(x, torch.Tensor) else x
 
 
 class GcPcSaft:
@@ -324,7 +343,7 @@ class GcPcSaft:
         ident = [s for s, _ in segment_records]
         par = np.stack([np.asarray(v, dtype=np.float64) for _, v in segment_records], axis=0)
         self.S = len(ident)
-        self.device = native._dev()
+        self.device = _device_of(phi)
         self.seg = torch.from_numpy(par).contiguous()
         self.rows = torch.from_numpy(encode_rows(ident, segments, bonds)).to(self.device)
         kab = torch.zeros((self.S, self.S), dtype=torch.float64)
@@ -351,8 +370,7 @@ class GcPcSaft:
             self._order = native.gc_class_order(self.table, self.S, self.rows)
         r = native.gc_bubble_dew(self.table, self.S, self.rows, self.phi, torch.from_numpy(t), torch.from_numpy(x),
                                  torch.from_numpy(p), dew, order=self._order)
-        status = r["status"].cpu().numpy()
-        return r["rho4"].cpu().numpy()[~status], status
+        return native.Compaction(r["status"]).gather(r["rho4"]).cpu().numpy(), r["status"].cpu().numpy()
 
     def bubble_point(self, temperature, liquid_molefracs, pressure):
         return self._solve(temperature, liquid_molefracs, pressure, False)

@@ -67,7 +67,128 @@ def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=Fal
                             _lib.ptr(rho_vl), _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws),
                             _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_pure_vle")
-    return {"p_sat": p_sat, "rho_eq": rho_eq, "rho_vl": rho_vl, "status": status.bool(), "iters": iters}
+    return {"p_sat": p_sat, "rho_eq": rho_eq, "rho_vl": rho_vl, "status": status.view(torch.bool), "iters": iters}
+
+
+def pure_vapor_pressure(params, temperature, want_rho_vl=False):
+    """PcSaftPure.vapor_pressure in one call (pcs_pure_vapor_pressure): always the pressure-only kernel, so p_sat has the
+    same bits with and without the densities.  -> dict(p_sat [Pa], rho_vl [n,2] A^-3 or None, status bool)."""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    params = _prep(params, device, (8,))
+    temperature = _prep(temperature, device)
+    n = temperature.shape[0]
+    _same_rows(n, parameters=params)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        p_sat = torch.empty(n, dtype=_F64, device=device)
+        rho_vl = torch.empty((n, 2), dtype=_F64, device=device) if want_rho_vl else None
+        status = torch.empty(n, dtype=torch.uint8, device=device)
+        ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
+        rc = L.pcs_pure_vapor_pressure(_lib.ptr(params), _lib.ptr(temperature), n, _lib.ptr(p_sat), _lib.ptr(rho_vl),
+                                       _lib.ptr(status), _lib.ptr(ws), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_pure_vapor_pressure")
+    return {"p_sat": p_sat, "rho_eq": None, "rho_vl": rho_vl, "status": status.view(torch.bool), "iters": None}
+
+
+class Compaction:
+    """Plan of one status mask (K8, csrc/compact_kernels.hip): which rows a property call keeps, in order.  Building it costs
+    two small kernels and ONE 4-byte read-back (`n_ok`) -- the only host synchronisation of a property call; `gather` /
+    `expand` are single kernels (no boolean-index gathers, no nonzero)."""
+
+    def __init__(self, status):
+        """status: bool or uint8 [n] on the GPU, True / 1 = dropped."""
+        if status.dtype == torch.bool:
+            status = status.view(torch.uint8)
+        if status.dtype != torch.uint8 or status.dim() != 1 or not status.is_cuda:
+            raise ValueError("status must be a bool / uint8 vector on the GPU")
+        self.status = status.contiguous()
+        self.n = int(status.shape[0])
+        self.device = status.device
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            self.cws = torch.empty(max(1, L.pcs_compact_workspace_bytes(self.n) // 4), dtype=torch.int32, device=self.device)
+            _lib.check(L.pcs_compact_plan(_lib.ptr(self.status), self.n, _lib.ptr(self.cws),
+                                          _lib.current_stream_ptr(self.device)), "pcs_compact_plan")
+        self.n_ok = int(self.cws[0].item()) if self.n else 0
+        self.all_ok = self.n_ok == self.n
+
+    def gather(self, x):
+        """Rows of x ([n] or [n, ...] float64, or uint8 rows of a multiple of 8 bytes) that are kept, in order."""
+        if self.all_ok:
+            return x
+        if x.shape[0] != self.n:
+            raise ValueError(f"tensor has {x.shape[0]} rows, the mask {self.n}")
+        x = x.contiguous()
+        tail = tuple(x.shape[1:])
+        if x.dtype == torch.uint8:
+            flat = x.view(self.n, -1)
+            if flat.shape[1] % 8:
+                raise ValueError("uint8 rows must be a multiple of 8 bytes")
+            return self.gather(flat.view(_F64)).view(torch.uint8).view((self.n_ok,) + tail)
+        if x.dtype != _F64:
+            raise TypeError(f"expected float64, got {x.dtype}")
+        width = 1
+        for d in tail:
+            width *= int(d)
+        out = torch.empty((self.n_ok,) + tail, dtype=_F64, device=self.device)
+        if self.n_ok and width:
+            L = _lib.lib()
+            with torch.cuda.device(self.device):
+                _lib.check(L.pcs_compact_rows(_lib.ptr(self.status), self.n, _lib.ptr(self.cws), _lib.ptr(x), width,
+                                              _lib.ptr(out), None, _lib.current_stream_ptr(self.device)), "pcs_compact_rows")
+        return out
+
+    def index(self):
+        """int32 [n_ok]: original row of every kept row."""
+        out = torch.empty(self.n_ok, dtype=torch.int32, device=self.device)
+        if self.n_ok:
+            L = _lib.lib()
+            with torch.cuda.device(self.device):
+                _lib.check(L.pcs_compact_rows(_lib.ptr(self.status), self.n, _lib.ptr(self.cws), None, 1, None, _lib.ptr(out),
+                                              _lib.current_stream_ptr(self.device)), "pcs_compact_rows")
+        return out
+
+    def expand(self, src, g=None, col0=0, ncol=None):
+        """Dense [n, ncol]: g[j] * src[j, col0:col0+ncol] in the row of the j-th kept entry, 0 in dropped rows (the scatter of
+        a backward pass fused with its Jacobian product).  src [n_ok] or [n_ok, k] float64; 1-D src gives a 1-D result."""
+        one_d = src.dim() == 1
+        src2 = src.contiguous().view(src.shape[0], -1)
+        stride = int(src2.shape[1])
+        ncol = stride - col0 if ncol is None else ncol
+        if src2.shape[0] != self.n_ok or (g is not None and g.shape[0] != self.n_ok):
+            raise ValueError("src / g must have one row per kept row")
+        out = torch.empty((self.n, ncol), dtype=_F64, device=self.device)
+        if self.n:
+            L = _lib.lib()
+            with torch.cuda.device(self.device):
+                _lib.check(L.pcs_expand_rows(None if self.all_ok else _lib.ptr(self.status), self.n, _lib.ptr(self.cws),
+                                             None if g is None else _lib.ptr(g.contiguous()), _lib.ptr(src2), stride, col0, ncol,
+                                             _lib.ptr(out), _lib.current_stream_ptr(self.device)), "pcs_expand_rows")
+        return out.view(self.n) if (one_d and ncol == 1) else out
+
+
+class _CompactRows(torch.autograd.Function):
+    """Differentiable row filter of a model (`reduce`): keeps the graph to the caller's parameter tensor like the reference's
+    boolean indexing (feos_torch/pcsaft_pure.py:235-243) without its nonzero / index kernels."""
+
+    @staticmethod
+    def forward(ctx, comp, x):
+        ctx.comp = comp
+        ctx.in_device = x.device
+        ctx.shape = tuple(x.shape)
+        return comp.gather(x.detach().to(comp.device)).to(x.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        comp = ctx.comp
+        g = g.to(comp.device).contiguous()
+        out = comp.expand(g.view(g.shape[0], -1) if g.dim() > 1 else g)
+        return None, out.view(ctx.shape).to(ctx.in_device)
+
+
+def compact_rows(comp, x):
+    """x[kept rows] with autograd (identity when every row is kept)."""
+    return x if comp.all_ok else _CompactRows.apply(comp, x)
 
 
 def pure_liquid_density(params, temperature, pressure):
@@ -88,7 +209,7 @@ def pure_liquid_density(params, temperature, pressure):
                                        _lib.ptr(rho), _lib.ptr(root), _lib.ptr(status),
                                        _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_pure_liquid_density")
-    return {"rho": rho, "rho_root": root, "status": status.bool()}
+    return {"rho": rho, "rho_root": root, "status": status.view(torch.bool)}
 
 
 def pure_derivatives(params, temperature, density):
@@ -141,10 +262,10 @@ class PcSaft:
         parameters = _as_f64(parameters, 2)
         temperature = _as_f64(temperature, 1)
         r = pure_vle(torch.from_numpy(parameters), torch.from_numpy(temperature), want_p=False)
-        status = r["status"].cpu().numpy()
-        rho = np.zeros((int((~status).sum()), 4))
-        rho[:, 0:2] = r["rho_vl"].cpu().numpy()[~status]
-        return rho, status
+        comp = Compaction(r["status"])  # failed rows dropped on the device (:93-101)
+        rho = np.zeros((comp.n_ok, 4))
+        rho[:, 0:2] = comp.gather(r["rho_vl"]).cpu().numpy()
+        return rho, r["status"].cpu().numpy()
 
     @staticmethod
     def liquid_density(parameters, temperature, pressure):
@@ -154,8 +275,7 @@ class PcSaft:
         pressure = _as_f64(pressure, 1)
         r = pure_liquid_density(torch.from_numpy(parameters), torch.from_numpy(temperature),
                                 torch.from_numpy(pressure))
-        status = r["status"].cpu().numpy()
-        return r["rho_root"].cpu().numpy()[~status], status
+        return Compaction(r["status"]).gather(r["rho_root"]).cpu().numpy(), r["status"].cpu().numpy()
 
 
 def _as_f64(x, ndim):
@@ -233,7 +353,7 @@ def mix_bubble_dew(params, kij, temperature, molefracs, pressure, dew, want_iter
                                   _lib.ptr(molefracs), _lib.ptr(pressure), n, _lib.ptr(p), _lib.ptr(rho4),
                                   _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws), _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_mix_bubble_dew")
-    return {"p": p, "rho4": rho4, "status": status.bool(), "iters": iters}
+    return {"p": p, "rho4": rho4, "status": status.view(torch.bool), "iters": iters}
 
 
 def mix_derivatives(params, kij, temperature, density):
@@ -263,8 +383,7 @@ def _pcsaft_bubble_dew(parameters, kij, temperature, molefracs, pressure, dew):
     temperature, molefracs, pressure = _as_f64(temperature, 1), _as_f64(molefracs, 1), _as_f64(pressure, 1)
     r = mix_bubble_dew(torch.from_numpy(parameters), torch.from_numpy(kij), torch.from_numpy(temperature),
                        torch.from_numpy(molefracs), torch.from_numpy(pressure), dew)
-    status = r["status"].cpu().numpy()
-    return r["rho4"].cpu().numpy()[~status], status
+    return Compaction(r["status"]).gather(r["rho4"]).cpu().numpy(), r["status"].cpu().numpy()  # filter_binary (:216-231)
 
 
 def _bubble_point(parameters, kij, temperature, liquid_molefracs, pressure):
@@ -371,7 +490,7 @@ def gc_bubble_dew(table, S, rows, phi, temperature, molefracs, pressure, dew, wa
                                  _lib.ptr(rho4), _lib.ptr(status), _lib.ptr(iters), _lib.ptr(order), _lib.ptr(ws),
                                  _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_gc_bubble_dew")
-    return {"p": p, "rho4": rho4, "status": status.bool(), "iters": iters}
+    return {"p": p, "rho4": rho4, "status": status.view(torch.bool), "iters": iters}
 
 
 def gc_derivatives(table, S, rows, phi, temperature, density):

@@ -15,8 +15,12 @@ from . import native
 
 
 class _BubbleDew(torch.autograd.Function):
+    """value[n_ok], nans[n] = bubble / dew pressure.  Dense solve, one compaction plan (its 4-byte row count is the call's only
+    host synchronisation), single-kernel gathers only when rows were dropped (native.Compaction; the reference drops them
+    inside the native call, src/pcsaft.rs:216-231)."""
+
     @staticmethod
-    def forward(ctx, dew, parameters, kij, temperature, molefracs, pressure):
+    def forward(ctx, dew, parameters, kij, temperature, molefracs, pressure, box):
         out_device = parameters.device
         dev = native._dev() if not parameters.is_cuda else parameters.device
         par = native._prep(parameters, dev, (2, 8))
@@ -26,20 +30,15 @@ class _BubbleDew(torch.autograd.Function):
         p0 = native._prep(pressure, dev)
         r = native.mix_bubble_dew(par, k, T, z, p0, dew)
         nans = r["status"]
-        all_ok = not bool(nans.any())  # every row converged: no compaction, no gathers
-        ok = None if all_ok else ~nans
-        value = r["p"] if all_ok else r["p"][ok]
+        comp = native.Compaction(nans)
+        box.append(comp)
+        value = comp.gather(r["p"])
         needs = list(ctx.needs_input_grad[1:4])
         if any(needs):
-            if all_ok:
-                jac = native.mix_jacobian(par, k, T, r["rho4"], dew)
-                ctx.save_for_backward(jac)
-            else:
-                jac = native.mix_jacobian(par[ok], k[ok], T[ok], r["rho4"][ok], dew)
-                ctx.save_for_backward(jac, ok)
-        ctx.all_ok = all_ok
+            jac = native.mix_jacobian(comp.gather(par), comp.gather(k), comp.gather(T), comp.gather(r["rho4"]), dew)
+            ctx.save_for_backward(jac)
+            ctx.comp = comp
         ctx.needs = needs
-        ctx.n = T.shape[0]
         ctx.in_devices = (parameters.device, kij.device, temperature.device)
         nans = nans.to(out_device)
         ctx.mark_non_differentiable(nans)
@@ -47,29 +46,18 @@ class _BubbleDew(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_value, _g_nans):
-        if ctx.all_ok:
-            (jac,) = ctx.saved_tensors
-            ok = None
-        else:
-            jac, ok = ctx.saved_tensors
-        g = g_value.to(jac.device)
-        n = ctx.n
-
-        def scatter(x, tail):
-            if ok is None:
-                return x
-            out = torch.zeros((n,) + tail, dtype=torch.float64, device=jac.device)
-            out[ok] = x
-            return out
-
+        (jac,) = ctx.saved_tensors
+        comp = ctx.comp
+        g = g_value.to(jac.device).contiguous()
+        n = comp.n
         gp = gk = gt = None
         if ctx.needs[0]:
-            gp = scatter(g[:, None] * jac[:, 0:16], (16,)).view(n, 2, 8).to(ctx.in_devices[0])
+            gp = comp.expand(jac, g, 0, 16).view(n, 2, 8).to(ctx.in_devices[0])
         if ctx.needs[1]:
-            gk = scatter(g[:, None] * jac[:, 16:18], (2,)).to(ctx.in_devices[1])
+            gk = comp.expand(jac, g, 16, 2).to(ctx.in_devices[1])
         if ctx.needs[2]:
-            gt = scatter(g * jac[:, 18], ()).to(ctx.in_devices[2])
-        return None, gp, gk, gt, None, None
+            gt = comp.expand(jac, g, 18, 1).view(n).to(ctx.in_devices[2])
+        return None, gp, gk, gt, None, None, None
 
 
 class _MixDerivatives(torch.autograd.Function):
@@ -128,14 +116,20 @@ class PcSaftMix:
     def _set(self, parameters, kij):
         self._par = parameters
         self.kij = kij
-        self.m = parameters[:, :, 0]
-        self.sigma = parameters[:, :, 1]
-        self.epsilon_k = parameters[:, :, 2]
-        self.mu2 = parameters[:, :, 3] ** 2 / (self.m * self.sigma**3 * self.epsilon_k) * 1e-19 * (1.0 / 1.380649e-23)
-        self.kappa_ab = parameters[:, :, 4]
-        self.epsilon_k_ab = parameters[:, :, 5]
-        self.na = parameters[:, :, 6]
-        self.nb = parameters[:, :, 7]
+
+    # attribute views of the reference (:14-29), computed on access (the kernels read the [N,2,8] array itself)
+    m = property(lambda self: self._par[:, :, 0])
+    sigma = property(lambda self: self._par[:, :, 1])
+    epsilon_k = property(lambda self: self._par[:, :, 2])
+    kappa_ab = property(lambda self: self._par[:, :, 4])
+    epsilon_k_ab = property(lambda self: self._par[:, :, 5])
+    na = property(lambda self: self._par[:, :, 6])
+    nb = property(lambda self: self._par[:, :, 7])
+
+    @property
+    def mu2(self):
+        p = self._par
+        return p[:, :, 3] ** 2 / (p[:, :, 0] * p[:, :, 1] ** 3 * p[:, :, 2]) * 1e-19 * (1.0 / 1.380649e-23)
 
     @property
     def parameters(self):
@@ -155,30 +149,39 @@ class PcSaftMix:
         temperature = torch.as_tensor(temperature, dtype=torch.float64)
         density = torch.as_tensor(density, dtype=torch.float64)
         if self.ncomp != 2:
+            if temperature.requires_grad or density.requires_grad:
+                raise NotImplementedError("the n-component state functions are forward only (binary mixtures are differentiable)")
             a, p, mu, v = native.mixn_derivatives(self._par, temperature, density)
             dev = self._par.device
             return a.to(dev), p.to(dev), mu.to(dev), v.to(dev)
         return _MixDerivatives.apply(self._par, self.kij, temperature, density)
 
-    def bubble_point(self, temperature, liquid_molefracs, pressure):
-        """(p [Pa], nans) at T [K], liquid mole fraction of component 1, initial pressure [Pa] (:422-444)."""
+    def _bubble_dew(self, dew, temperature, molefracs, pressure):
         if self.ncomp != 2:
             raise Exception("bubble and dew points are implemented for binary mixtures (src/pcsaft.rs:43-79 takes [N,2,8])")
-        value, nans = _BubbleDew.apply(False, self._par, self.kij, temperature, liquid_molefracs, pressure)
-        self.reduce(nans)
+        box = []
+        # mole fractions and initial pressure do not enter the reference's final formula (:435-444): no gradient flows to them
+        value, nans = _BubbleDew.apply(dew, self._par, self.kij, temperature, _detached(molefracs), _detached(pressure), box)
+        self._reduce(box[0])
         return value, nans
+
+    def bubble_point(self, temperature, liquid_molefracs, pressure):
+        """(p [Pa], nans) at T [K], liquid mole fraction of component 1, initial pressure [Pa] (:422-444)."""
+        return self._bubble_dew(False, temperature, liquid_molefracs, pressure)
 
     def dew_point(self, temperature, vapor_molefracs, pressure):
         """(p [Pa], nans) at T [K], vapour mole fraction of component 1, initial pressure [Pa] (:446-468)."""
-        if self.ncomp != 2:
-            raise Exception("bubble and dew points are implemented for binary mixtures (src/pcsaft.rs:43-79 takes [N,2,8])")
-        value, nans = _BubbleDew.apply(True, self._par, self.kij, temperature, vapor_molefracs, pressure)
-        self.reduce(nans)
-        return value, nans
+        return self._bubble_dew(True, temperature, vapor_molefracs, pressure)
+
+    def _reduce(self, comp):
+        if not comp.all_ok:
+            self._set(native.compact_rows(comp, self._par), None if self.kij is None else native.compact_rows(comp, self.kij))
 
     def reduce(self, nans):
         """Drop the rows flagged in ``nans`` (:470-479)."""
-        if not bool(nans.any()):
-            return
-        keep = ~nans.to(self._par.device)
-        self._set(self._par[keep], self.kij[keep.to(self.kij.device)])
+        dev = self._par.device if self._par.is_cuda else native._dev()
+        self._reduce(native.Compaction(nans.to(dev)))
+
+
+def _detached(x):
+    return x.detach() if isinstance(x, torch.Tensor) else x

@@ -19,46 +19,48 @@ from . import native
 
 
 class _PureProperty(torch.autograd.Function):
-    """value[n_ok], nans[n] = property(parameters[n,8], temperature[n], pressure[n] or None)"""
+    """value[n_ok], nans[n] = property(parameters[n,8], temperature[n], pressure[n] or None)
+
+    One solve (dense outputs + status byte per row), one compaction plan whose 4-byte row count is the call's only host
+    synchronisation, then -- only if rows were dropped -- single-kernel gathers (native.Compaction; the reference drops
+    the rows inside its native call, src/pcsaft.rs:93-101).  The forward value does not depend on whether a gradient is
+    requested: the vapour pressure always comes from the pressure-only kernel (pcs_pure_vapor_pressure)."""
 
     @staticmethod
-    def forward(ctx, which, parameters, temperature, pressure):
+    def forward(ctx, which, parameters, temperature, pressure, box):
         out_device = parameters.device
         dev = native._dev() if not parameters.is_cuda else parameters.device
         par = native._prep(parameters, dev, (8,))
         T = native._prep(temperature, dev)
+        needs = list(ctx.needs_input_grad[1:4])
         if which == "liquid_density":
             P = native._prep(pressure, dev)
             r = native.pure_liquid_density(par, T, P)
             value = r["rho"]
-            rho_vl = torch.stack([torch.zeros_like(r["rho_root"]), r["rho_root"]], dim=1)
+            rho_vl = None
+        elif which == "vapor_pressure":
+            P = None
+            r = native.pure_vapor_pressure(par, T, want_rho_vl=any(needs))
+            value, rho_vl = r["p_sat"], r["rho_vl"]
         else:
             P = None
-            # the converged densities are only needed by the Jacobian kernel
-            r = native.pure_vle(par, T, want_p=(which == "vapor_pressure"),
-                                want_rho_eq=(which == "equilibrium_liquid_density"),
-                                want_rho_vl=any(ctx.needs_input_grad[1:4]))
-            value = r["p_sat"] if which == "vapor_pressure" else r["rho_eq"]
-            rho_vl = r["rho_vl"]
+            r = native.pure_vle(par, T, want_p=False, want_rho_eq=True, want_rho_vl=any(needs))
+            value, rho_vl = r["rho_eq"], r["rho_vl"]
         nans = r["status"]
-        # every row converged (the common case): no compaction, no gathers
-        all_ok = not bool(nans.any())
-        ok = None if all_ok else ~nans
-        if not all_ok:
-            value = value[ok]
-        needs = list(ctx.needs_input_grad[1:4])
+        comp = native.Compaction(nans)
+        box.append(comp)  # handed to the model for its `reduce`
+        value = comp.gather(value)
         if any(needs):
             # Jacobian only on converged rows (dense kernel on the compacted inputs)
-            if all_ok:
-                jac = native.pure_jacobian(which, par, T, P, rho_vl)
-                ctx.save_for_backward(jac)
+            if which == "liquid_density":
+                root = comp.gather(r["rho_root"])
+                rho_vl = torch.stack([torch.zeros_like(root), root], dim=1)
             else:
-                jac = native.pure_jacobian(which, par[ok], T[ok], None if P is None else P[ok], rho_vl[ok])
-                ctx.save_for_backward(jac, ok)
-        ctx.all_ok = all_ok
+                rho_vl = comp.gather(rho_vl)
+            jac = native.pure_jacobian(which, comp.gather(par), comp.gather(T), None if P is None else comp.gather(P), rho_vl)
+            ctx.save_for_backward(jac)
+            ctx.comp = comp
         ctx.needs = needs
-        ctx.n = T.shape[0]
-        ctx.out_device = out_device
         ctx.in_devices = (parameters.device, temperature.device, None if pressure is None else pressure.device)
         nans = nans.to(out_device)
         ctx.mark_non_differentiable(nans)
@@ -66,29 +68,18 @@ class _PureProperty(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_value, _g_nans):
-        if ctx.all_ok:
-            (jac,) = ctx.saved_tensors
-            ok = None
-        else:
-            jac, ok = ctx.saved_tensors
-        g = g_value.to(jac.device)
-        n = ctx.n
-
-        def scatter(x, tail):
-            if ok is None:
-                return x
-            out = torch.zeros((n,) + tail, dtype=torch.float64, device=jac.device)
-            out[ok] = x
-            return out
-
+        (jac,) = ctx.saved_tensors
+        comp = ctx.comp
+        g = g_value.to(jac.device).contiguous()
         gp = gt = gpr = None
+        # dense gradient rows in one kernel each: g_j * jac[j, cols] scattered to the row's place, zeros for dropped rows
         if ctx.needs[0]:
-            gp = scatter(g[:, None] * jac[:, 0:8], (8,)).to(ctx.in_devices[0])
+            gp = comp.expand(jac, g, 0, 8).to(ctx.in_devices[0])
         if ctx.needs[1]:
-            gt = scatter(g * jac[:, 8], ()).to(ctx.in_devices[1])
+            gt = comp.expand(jac, g, 8, 1).view(comp.n).to(ctx.in_devices[1])
         if ctx.needs[2]:
-            gpr = scatter(g * jac[:, 9], ()).to(ctx.in_devices[2])
-        return None, gp, gt, gpr
+            gpr = comp.expand(jac, g, 9, 1).view(comp.n).to(ctx.in_devices[2])
+        return None, gp, gt, gpr, None
 
 
 class _PureDerivatives(torch.autograd.Function):
@@ -125,19 +116,23 @@ class PcSaftPure:
         (feos_torch/pcsaft_pure.py:90-104, README.md:12)."""
         if parameters.dim() != 2 or parameters.shape[1] != 8:
             raise ValueError("parameters must have shape [N, 8]")
-        self._set(parameters)
-
-    def _set(self, parameters):
         self._par = parameters
-        # attribute views kept for source compatibility with the reference (:91-104)
-        self.m = parameters[:, 0]
-        self.sigma = parameters[:, 1]
-        self.epsilon_k = parameters[:, 2]
-        self.mu2 = parameters[:, 3] ** 2 / (self.m * self.sigma**3 * self.epsilon_k) * 1e-19 * (1.0 / 1.380649e-23)
-        self.kappa_ab = parameters[:, 4]
-        self.epsilon_k_ab = parameters[:, 5]
-        self.na = parameters[:, 6]
-        self.nb = parameters[:, 7]
+
+    # attribute views of the reference (:91-104), computed on access: the kernels read the [N,8] array itself, and
+    # `mu2` alone is six strided passes over it (0.6 ms per 1e7 rows on every construction and every `reduce` if eager)
+    m = property(lambda self: self._par[:, 0])
+    sigma = property(lambda self: self._par[:, 1])
+    epsilon_k = property(lambda self: self._par[:, 2])
+    kappa_ab = property(lambda self: self._par[:, 4])
+    epsilon_k_ab = property(lambda self: self._par[:, 5])
+    na = property(lambda self: self._par[:, 6])
+    nb = property(lambda self: self._par[:, 7])
+
+    @property
+    def mu2(self):
+        """mu^2 / (m sigma^3 epsilon_k) * 1e-19 / k_B (:94-99)."""
+        p = self._par
+        return p[:, 3] ** 2 / (p[:, 0] * p[:, 1] ** 3 * p[:, 2]) * 1e-19 * (1.0 / 1.380649e-23)
 
     @property
     def parameters(self):
@@ -157,25 +152,29 @@ class PcSaftPure:
         return _PureDerivatives.apply(self._par, temperature, density)
 
     # -- properties ------------------------------------------------------------------------
+    def _property(self, which, temperature, pressure):
+        box = []
+        value, nans = _PureProperty.apply(which, self._par, temperature, pressure, box)
+        self._reduce(box[0])
+        return nans, value
+
     def liquid_density(self, temperature, pressure):
         """(nans, rho [kmol/m3]) at (T [K], p [Pa]) (:184-199)."""
-        value, nans = _PureProperty.apply("liquid_density", self._par, temperature, pressure)
-        self.reduce(nans)
-        return nans, value
+        return self._property("liquid_density", temperature, pressure)
 
     def vapor_pressure(self, temperature):
         """(nans, p_sat [Pa]) at T [K] (:201-215)."""
-        value, nans = _PureProperty.apply("vapor_pressure", self._par, temperature, None)
-        self.reduce(nans)
-        return nans, value
+        return self._property("vapor_pressure", temperature, None)
 
     def equilibrium_liquid_density(self, temperature):
         """(nans, saturated liquid density [kmol/m3]) at T [K] (:217-233)."""
-        value, nans = _PureProperty.apply("equilibrium_liquid_density", self._par, temperature, None)
-        self.reduce(nans)
-        return nans, value
+        return self._property("equilibrium_liquid_density", temperature, None)
+
+    def _reduce(self, comp):
+        if not comp.all_ok:
+            self._par = native.compact_rows(comp, self._par)
 
     def reduce(self, nans):
         """Drop the rows flagged in ``nans`` from the model (:235-243)."""
-        if bool(nans.any()):
-            self._set(self._par[~nans.to(self._par.device)])
+        dev = self._par.device if self._par.is_cuda else native._dev()
+        self._reduce(native.Compaction(nans.to(dev)))

@@ -69,6 +69,17 @@ int pcs_pure_vle_retry(const double* params, const double* temp, int64_t n, doub
                        double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);
 
 /*
+ * PcSaftPure.vapor_pressure as ONE call (feos_torch/pcsaft_pure.py:201-215 incl. its Rust solve, src/pcsaft.rs:82-103):
+ * always the pressure-only kernel of pcs_pure_vle (fp32 pre-solve, fp64 finish), so p_sat carries the same bits whether
+ * or not the caller also asks for the densities.
+ *   rho_vl [n,2] out (optional) the densities the last fp64 Newton step of that kernel ended on: ~1e-9 (relative) from the
+ *                root -- what the Jacobian kernel needs; p_sat is second order in that error.  For densities converged to
+ *                ~1e-12 (the reference's rho output) call pcs_pure_vle with rho_vl.
+ */
+int pcs_pure_vapor_pressure(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_vl,
+                            uint8_t* status, void* workspace, void* stream);
+
+/*
  * Liquid density at given (T, p).
  * Replaces PcSaft.liquid_density(parameters[N,8], temperature[N], pressure[N]) ->
  * (rho[n_ok], status[N]) (src/pcsaft.rs:28-41, :105-129) and the tail of
@@ -236,6 +247,26 @@ int pcs_mix_derivatives_vjp(const double* params, const double* kij, const doubl
 int pcs_gc_derivatives_vjp(const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,
                            const double* rho, int64_t n, const double* g_a, const double* g_p, const double* g_mu,
                            const double* g_v, double* grad_seg, double* jac9, double* agg, const int32_t* order, void* stream);
+
+/*
+ * Order-preserving stream compaction of dense solver outputs.  The reference drops the rows its solver
+ * fails on inside the native call (src/pcsaft.rs:93-101, :216-231: `rho[n_ok, ..]` + `status[N]`) and filters the model
+ * with the same mask (feos_torch/pcsaft_pure.py:235-243, pcsaft_mix.py:470-479, gc_pcsaft.py:514-528).
+ *   pcs_compact_workspace_bytes(n)  bytes of the plan buffer `cws`
+ *   pcs_compact_plan    status [n] (uint8, 0 = keep) -> cws; afterwards ((int32_t*)cws)[0] = number of kept rows (the one
+ *                       value a caller has to read back to size its outputs)
+ *   pcs_compact_rows    dst[j, 0..width) = src[i_j, 0..width) for the j-th kept row, rows of `width` doubles (1..64);
+ *                       index [n_ok] (int32, optional) = i_j.  src / dst may be NULL together (index only).
+ *   pcs_expand_rows     inverse, fused with the chain rule of the backward pass: dst[i, c] = g[j] * src[j, col0 + c]
+ *                       (c < ncol) for kept rows, 0 for dropped ones; src rows have src_stride doubles; g NULL = 1;
+ *                       status NULL = every row kept (j = i, cws unused).
+ */
+int64_t pcs_compact_workspace_bytes(int64_t n);
+int pcs_compact_plan(const uint8_t* status, int64_t n, void* cws, void* stream);
+int pcs_compact_rows(const uint8_t* status, int64_t n, const void* cws, const double* src, int width, double* dst,
+                     int32_t* index, void* stream);
+int pcs_expand_rows(const uint8_t* status, int64_t n, const void* cws, const double* g, const double* src, int src_stride,
+                    int col0, int ncol, double* dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,10 +40,46 @@ def _stale():
     return False
 
 
+FAST_FLAGS = "-O3 -march=native (default fp contraction), OpenMP"
+PARITY_FLAGS = "-O2 -ffp-contract=off, OpenMP"
+
+
+def _cpu_key():
+    """Short hash of this host's CPU model + ISA flags: a -march=native build must not travel to another machine."""
+    import hashlib
+
+    model, flags = "", ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and not model:
+                    model = line
+                elif line.startswith("flags") and not flags:
+                    flags = line
+    except OSError:
+        pass
+    return hashlib.sha1((model + flags).encode()).hexdigest()[:12]
+
+
+def use_fast_build():
+    """bench.py's cpu_baseline leg only: switch this process to the performance build of the same sources
+    (oracle/Makefile `fast`: -O3 -march=native), compiled here for this host's CPU.  Must be called before the first
+    oracle call of the process; parity tests never call it."""
+    global _LIB_PATH
+    assert _lib is None, "use_fast_build() must come before the first oracle call"
+    out = os.path.join(_HERE, "_build", f"liboracle_fast.{_cpu_key()}.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".hpp", ".cpp"))]
+    if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "fast", f"FAST_OUT={os.path.relpath(out, _HERE)}"])
+    _LIB_PATH = out
+    return out
+
+
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if _LIB_PATH.endswith("liboracle.so"):
+            build()
         L = ctypes.CDLL(_LIB_PATH)
         L.orc_num_threads.restype = _int
         L.orc_dual3_selftest.restype = _int

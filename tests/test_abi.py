@@ -47,6 +47,9 @@ def test_argument_validation_without_gpu(hip_lib):
     one = ctypes.c_void_p(8)  # never dereferenced: the checks come first
     calls = {
         "pcs_pure_vle": lambda n, req: L.pcs_pure_vle(req, req, n, nul, nul, nul, req, nul, req, nul),
+        "pcs_pure_vapor_pressure": lambda n, req: L.pcs_pure_vapor_pressure(req, req, n, nul, nul, req, req, nul),
+        "pcs_compact_rows": lambda n, req: L.pcs_compact_rows(req, n, req, req, 8, req, nul, nul),
+        "pcs_expand_rows": lambda n, req: L.pcs_expand_rows(req, n, req, nul, req, 10, 0, 8, req, nul),
         "pcs_pure_liquid_density": lambda n, req: L.pcs_pure_liquid_density(req, req, req, n, nul, nul, req, nul),
         "pcs_pure_derivatives": lambda n, req: L.pcs_pure_derivatives(req, req, req, n, nul, nul, nul, nul),
         "pcs_mix_bubble_dew": lambda n, req: L.pcs_mix_bubble_dew(0, req, req, req, req, req, n, nul, nul, req, nul, nul, nul),
@@ -59,6 +62,10 @@ def test_argument_validation_without_gpu(hip_lib):
         for n, req in ((-1, one), (1 << 31, one), (5, nul)):
             assert call(n, req) != 0, (name, n)
             assert L.pcs_last_error() != b"", name
+    assert L.pcs_compact_plan(nul, 5, one, nul) != 0 and L.pcs_compact_plan(one, 5, nul, nul) != 0
+    assert L.pcs_compact_rows(one, 5, one, one, 0, one, nul, nul) != 0 and b"width" in L.pcs_last_error()
+    assert L.pcs_expand_rows(one, 5, one, nul, one, 10, 4, 8, one, nul) != 0 and b"column" in L.pcs_last_error()
+    assert L.pcs_compact_workspace_bytes(10_000_000) == 4 * (2 + 4883 + 2)
     assert L.pcs_pure_jacobian(7, one, one, nul, one, 5, one, nul) != 0  # unknown property selector
     assert b"which" in L.pcs_last_error()
 
