@@ -34,6 +34,8 @@ SIGNATURES = {
     "pcs_pure_liquid_density": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pcs_pure_derivatives": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pcs_pure_jacobian": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "pcs_pure_jacobian_vjp": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "pcs_mix_workspace_bytes": (_i64, [_i64]),
     "pcs_mix_bubble_dew": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_mix_jacobian": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "pcs_gc_table_doubles": (_i64, [_int]),

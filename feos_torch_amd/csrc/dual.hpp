@@ -347,6 +347,22 @@ template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator+(const T& b, const T1<T
 template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator-(const T1<T>& a, const T& b) { return T1<T>(a.v - b, a.g0, a.g1); }
 template <class T, PCS_IFDUAL(T)> PCS_DEV T1<T> operator-(const T& b, const T1<T>& a) { return T1<T>(b - a.v, -a.g0, -a.g1); }
 
+// ---- D2 (x) T2: functions of the FIRST coordinate only ---------------------------------------------------------------
+// The solvers' evaluation takes its two-variable Taylor coefficients in the coordinates (zeta_3, rho_2) instead of
+// (rho_1, rho_2) (mix_solver.hpp::phase_eval_inline).  Everything that depends on the packing fraction alone -- 1/(1 - zeta_3)
+// and its powers, ln(1 - zeta_3), the dispersion and dipole polynomials, the pieces of C1 -- is then a function of the
+// first coordinate only: value, first and second derivative (a D2) instead of six numbers, D2 x D2 products (6 flops) among
+// themselves and 11-flop products with general T2 quantities instead of 17.  A D2 z stands for the T2 (z.v, z.d1, 0, z.d2, 0, 0).
+template <class T> PCS_DEV T2<T> operator*(const T2<T>& a, const D2<T>& b) {
+    return T2<T>(a.v * b.v, a.g0 * b.v + a.v * b.d1, a.g1 * b.v, a.h00 * b.v + 2.0 * (a.g0 * b.d1) + a.v * b.d2,
+                 a.h01 * b.v + a.g1 * b.d1, a.h11 * b.v);
+}
+template <class T> PCS_DEV T2<T> operator*(const D2<T>& b, const T2<T>& a) { return a * b; }
+template <class T> PCS_DEV T2<T> operator+(const T2<T>& a, const D2<T>& b) { return T2<T>(a.v + b.v, a.g0 + b.d1, a.g1, a.h00 + b.d2, a.h01, a.h11); }
+template <class T> PCS_DEV T2<T> operator+(const D2<T>& b, const T2<T>& a) { return a + b; }
+template <class T> PCS_DEV T2<T> operator-(const T2<T>& a, const D2<T>& b) { return T2<T>(a.v - b.v, a.g0 - b.d1, a.g1, a.h00 - b.d2, a.h01, a.h11); }
+template <class T> PCS_DEV T2<T> operator-(const D2<T>& b, const T2<T>& a) { return T2<T>(b.v - a.v, b.d1 - a.g0, -a.g1, b.d2 - a.h00, -a.h01, -a.h11); }
+
 // second-order <-> first-order two-variable types (drop / zero the Hessian part)
 template <class T> PCS_DEV T1<T> lower(const T2<T>& a) { return T1<T>(a.v, a.g0, a.g1); }
 template <class T> PCS_DEV T2<T> raise(const T1<T>& a) { return T2<T>(a.v, a.g0, a.g1, T(0.0), T(0.0), T(0.0)); }

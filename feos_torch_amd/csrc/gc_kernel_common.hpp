@@ -15,6 +15,7 @@ template <class P>
 struct GcModelT {
     GcCoef<P> c;
     template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return gc_a<P, R>(c, r0, r1); }
+    template <class R, class Z> PCS_DEV R a_z(const R& r0, const R& r1, const Z& zeta3) const { return gc_a_z<P, R, Z>(c, r0, r1, zeta3); }
     PCS_DEV double packing(double x0, double x1) const { return x0 * re(c.zk[3][0]) + x1 * re(c.zk[3][1]); }
 };
 

@@ -269,11 +269,13 @@ PCS_DEV void gc_cross_refine(T2<T>& xa0, T2<T>& xa1, const T2<T>& d00, const T2<
     xa1 = xa1 - dx1;
 }
 
-template <class P, class R>
-PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
-    Packing<R> pk;
-    R a = core_terms(c, r0, r1, pk);
-    const R &zeta2 = pk.zeta2, &z3m1 = pk.z3m1;
+// zeta3: the packing fraction as Z (R in general, D2<double> in the solvers' (zeta_3, rho_2) coordinates: mix_model.hpp Packing)
+template <class P, class R, class Z>
+PCS_DEV R gc_a_z(const GcCoef<P>& c, const R& r0, const R& r1, const Z& zeta3) {
+    Packing<R, Z> pk;
+    R a = core_terms_z<GcCoef<P>, R, Z>(c, r0, r1, zeta3, pk);
+    const R& zeta2 = pk.zeta2;
+    const Z& z3m1 = pk.z3m1;
 
     // hard chain over bond types (:156-165): g = 1/(1-z3) + 3 c d_ab + 2 (c d_ab)^2 (1 - z3)
     R cc = zeta2 * pk.z3m2;
@@ -355,6 +357,10 @@ PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
         }
     }
     return a;
+}
+template <class P, class R>
+PCS_DEV R gc_a(const GcCoef<P>& c, const R& r0, const R& r1) {
+    return gc_a_z<P, R, R>(c, r0, r1, r0 * c.zk[3][0] + r1 * c.zk[3][1]);
 }
 
 }  // namespace pcs

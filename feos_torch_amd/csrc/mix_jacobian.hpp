@@ -53,6 +53,7 @@ PCS_DEV int mix_direction(int pass, int j) {
 struct MixModelD {
     MixCoef<double> c;
     template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return mix_a<double, R>(c, r0, r1); }
+    template <class R, class Z> PCS_DEV R a_z(const R& r0, const R& r1, const Z& zeta3) const { return mix_a_z<double, R, Z>(c, r0, r1, zeta3); }
     PCS_DEV double packing(double x0, double x1) const { return x0 * c.zk[3][0] + x1 * c.zk[3][1]; }
 };
 

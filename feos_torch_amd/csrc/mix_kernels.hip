@@ -13,14 +13,6 @@
 #include <cstddef>
 #include "mix_solver.hpp"
 #include "mix_solver_sm.hpp"
-#ifndef PCS_MIX_SM
-#define PCS_MIX_SM 1  // 1: state-machine form of the solver (mix_solver_sm.hpp), 0: sequential form
-#endif
-#if PCS_MIX_SM
-#define PCS_BD_SOLVE bubble_dew_solve_sm
-#else
-#define PCS_BD_SOLVE bubble_dew_solve
-#endif
 #include "mix_jacobian.hpp"
 
 using namespace pcs;
@@ -28,52 +20,12 @@ using namespace pcs_abi;
 
 namespace {
 
-#ifndef PCS_MBLOCK
-#define PCS_MBLOCK 128
-#endif
-constexpr int MBLOCK = PCS_MBLOCK;
+constexpr int MBLOCK = 128;
 
-// PCS_MIX_PRELOAD = 1 (experiment, off): all coefficient loads of the evaluation function issued up front.  The ten
-// s_waitcnt of the function become one; SQ_WAIT_ANY drops 8.6e8 -> 6.9e8 quad-cycles per dew launch and SQ_WAIT_INST_ANY
-// rises by as much -- the kernel time does not move (2.84 / 6.44 ms vs 2.81 / 6.43 ms).  The single resident wave is
-// stalled by instruction dependencies, not by these loads.
-#ifndef PCS_MIX_PRELOAD
-#define PCS_MIX_PRELOAD 0
-#endif
 struct MixModel {
     MixCoef<double> c;
-#if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2  // diagnostics builds: evaluation counters
-    mutable int n_line = 0, n_phase = 0;
-    template <class R> PCS_DEV R a(const R& r0, const R& r1) const {
-        if (sizeof(R) == sizeof(T2<double>)) n_phase++; else n_line++;
-        return mix_a<double, R>(c, r0, r1);
-    }
-#else
-    template <class R> PCS_DEV R a(const R& r0, const R& r1) const {
-#if PCS_MIX_PRELOAD
-        // The solvers' evaluation function receives the model by reference (private memory).  Left to the compiler its
-        // ~37 loads sit in ten groups next to their uses, each followed by s_waitcnt: ten exposed memory round trips per
-        // call with one wave per SIMD (SQ_WAIT_ANY = 23 % of the wave cycles).  Here every coefficient the row needs is
-        // read up front -- the empty asm statements keep the loads above them and their results in registers -- so one
-        // round trip is exposed instead.  (Volatile loads do not do it: the backend waits after each of them.)
-        if (sizeof(R) == sizeof(T2<double>)) {
-            MixCoef<double> l;
-            const double* src = reinterpret_cast<const double*>(&c);
-            double* dst = reinterpret_cast<double*>(&l);
-            constexpr int N = sizeof(MixCoef<double>) / 8;
-            static_assert(offsetof(MixCoef<double>, polar) % 8 == 0 && offsetof(MixCoef<double>, acls) % 8 == 0, "flag slots");
-            // (pj, tj of a non-polar row hold whatever mix_coef left there: loaded all the same, never used)
-#pragma unroll
-            for (int k = 0; k < N; k++) dst[k] = src[k];
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < N; k++) asm volatile("" : "+v"(dst[k]));
-            return mix_a<double, R>(l, r0, r1);
-        }
-#endif
-        return mix_a<double, R>(c, r0, r1);
-    }
-#endif
+    template <class R> PCS_DEV R a(const R& r0, const R& r1) const { return mix_a<double, R>(c, r0, r1); }
+    template <class R, class Z> PCS_DEV R a_z(const R& r0, const R& r1, const Z& zeta3) const { return mix_a_z<double, R, Z>(c, r0, r1, zeta3); }
     PCS_DEV double packing(double x0, double x1) const { return x0 * c.zk[3][0] + x1 * c.zk[3][1]; }
 };
 
@@ -91,24 +43,12 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
     k1 = kk.y;
 }
 
-#ifndef PCS_MIX_QUEUE
-#define PCS_MIX_QUEUE 1  // 1: class-ordered work queue with persistent waves, 0: fast pass + retry pass
-#endif
-#ifndef PCS_INPLACE_ROBUST
-#define PCS_INPLACE_ROBUST 1  // 0 (A/B builds): the work-queue kernel does not restart failed rows
-#endif
+// lanes that must be idle before a queue wave refills: the refill code (row load, coefficient set-up) runs for the whole
+// wave (A/B dew 1e6 rows, round 1, one kernel: 1: 7.9 ms, 4: 7.7, 8: 7.5, 16: 7.8; round 3, two kernels: 8: 4.93, 12: 4.84, 16: 4.83, 24: 4.89)
 #ifndef PCS_REFILL_MIN
-#define PCS_REFILL_MIN 8  // lanes that must be idle before the wave refills (A/B dew 1e6 rows: 1: 7.9 ms, 4: 7.7, 8: 7.5, 16: 7.8)
+#define PCS_REFILL_MIN 16
 #endif
-#ifndef PCS_QUEUE_WAVES_PER_SIMD
-#define PCS_QUEUE_WAVES_PER_SIMD 1
-#endif
-#ifndef PCS_FAST_SS
-#define PCS_FAST_SS 12
-#define PCS_FAST_NEWTON 12
-#endif
-constexpr int FAST_SS = PCS_FAST_SS, FAST_NEWTON = PCS_FAST_NEWTON;  // iteration caps of the fast pass (see mix_solver.hpp)
-constexpr int MIX_RETRY_GRID = 2048;             // 64-thread workgroups of the robust pass
+constexpr int REFILL_MIN = PCS_REFILL_MIN;
 
 constexpr int MIX_BINS = 8;
 // association class (none, self, induced, cross: mix_model.hpp) x polarity of a parameter row [2][8]
@@ -136,28 +76,21 @@ __device__ __forceinline__ void mix_store(int64_t i, int rc, const MixResult& r,
         double l0 = DEW ? r.inc0 : r.spec0, l1 = DEW ? r.inc1 : r.spec1;
         reinterpret_cast<double4*>(rho4)[i] = ok ? make_double4(v0, v1, l0, l1) : make_double4(0.0, 0.0, 0.0, 0.0);
     }
-#ifdef PCS_MIX_DIAG
-    if (iters) iters[i] = r.iters;
-#else
     if (iters) iters[i] = ok ? r.iters : -1;
-#endif
     status[i] = ok ? 0 : 1;
 }
 
-// K5 fast pass: small iteration caps; rows that hit a cap go to the retry list (retry[0] = count).
-// retry == nullptr: single pass with the full caps.
-#ifndef MIX_WAVES
-#define MIX_WAVES 1  // the non-inlined evaluation needs the whole register file
-#endif
+// K5 without a workspace: one row per lane in a single pass with the full iteration caps, the robust second attempt in
+// place.  Same arithmetic as the work-queue schedule below (tests/test_mix_missed_gpu.py), several times slower: a wave
+// pays its slowest row.
 template <bool DEW>
-__global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const double* __restrict__ params,
+__global__ __launch_bounds__(MBLOCK, 1) void k_mix_bubble_dew(const double* __restrict__ params,
                                                            const double* __restrict__ kij,
                                                            const double* __restrict__ temp,
                                                            const double* __restrict__ z,
                                                            const double* __restrict__ p_init, int64_t n,
                                                            double* __restrict__ p_out, double* __restrict__ rho4,
-                                                           uint8_t* __restrict__ status, int32_t* __restrict__ iters,
-                                                           int32_t* __restrict__ retry) {
+                                                           uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
     // bucket the rows of the workgroup by association class and polarity (LDS counting sort) so the lanes of
     // a wave mostly run the same branches of the Helmholtz energy: the cross-association site-fraction solve
     // costs ~5x the rest of an evaluation and would otherwise be paid by every wave
@@ -192,78 +125,10 @@ __global__ __launch_bounds__(MBLOCK, MIX_WAVES) void k_mix_bubble_dew(const doub
     mix_coef<double>(m.c, par, k0, k1, T);
     MixResult r;
     const double p_red = p_init[i] / (T * P_UNIT);
-#ifdef PCS_MIX_DIAG
-    long long t0 = clock64();
-#endif
-#if PCS_MIX_SM
     bool root_failed = false;
-    int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, retry ? FAST_SS : SS_MAX_IT, retry ? FAST_NEWTON : NEWTON_MAX_IT, false, &root_failed);
-    // single pass without a work list (workspace == NULL): the robust second attempt runs in place
-    if (!retry && rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
-#else
-    int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, retry ? FAST_SS : SS_MAX_IT, retry ? FAST_NEWTON : NEWTON_MAX_IT);
-#endif
-#ifdef PCS_MIX_DIAG
-#if PCS_MIX_DIAG == 3
-    // r.iters already holds the evaluation count
-#elif PCS_MIX_DIAG == 2
-    r.iters = m.n_phase | (m.n_line << 12);
-#else
-    r.iters = (int)((clock64() - t0) >> 10);  // diagnostics builds: per-row solve time in 1024-cycle units
-#endif
-    if (rc == BD_CAP && iters) iters[i] = r.iters;
-#endif
-    if (rc == BD_CAP) {
-        status[i] = 1;  // provisional
-        const int slot = atomicAdd(&retry[0], 1);
-        if (slot >= 0 && slot < n) retry[1 + slot] = (int32_t)i;  // bounded append (see pure_kernels.hip)
-        return;
-    }
+    int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, false, &root_failed);
+    if (rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
     mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
-}
-
-// K5 second pass over a compacted list (count read on the device; PCS_MIX_QUEUE = 0 builds): the rows that hit a cap of the
-// fast pass, same arithmetic with the full caps, then -- as everywhere -- the robust attempt for rows that still fail
-template <bool DEW>
-__global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const double* __restrict__ params,
-                                                             const double* __restrict__ kij,
-                                                             const double* __restrict__ temp,
-                                                             const double* __restrict__ z,
-                                                             const double* __restrict__ p_init,
-                                                             double* __restrict__ p_out, double* __restrict__ rho4,
-                                                             uint8_t* __restrict__ status, int32_t* __restrict__ iters,
-                                                             const int32_t* __restrict__ retry, int64_t n) {
-    const int count = (int)min((int64_t)max(retry[0], 0), n);  // count and entries bounded by n: a foreign list must not fault
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-        const int64_t i = retry[1 + k];
-        if (i < 0 || i >= n) continue;
-        double par[16], k0, k1;
-        load_mix_row(params, kij, i, par, k0, k1);
-        const double T = temp[i];
-        MixModel m;
-        mix_coef<double>(m.c, par, k0, k1, T);
-        MixResult r;
-#ifdef PCS_MIX_DIAG
-        long long t0 = clock64();
-#endif
-#if PCS_MIX_SM
-        bool root_failed = false;
-        int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r, SS_MAX_IT, NEWTON_MAX_IT, false, &root_failed);
-        if (rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r, SS_MAX_IT, NEWTON_MAX_IT, true);
-#else
-        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_init[i] / (T * P_UNIT), r);
-#endif
-#ifdef PCS_MIX_DIAG
-#if PCS_MIX_DIAG == 3
-        r.iters |= (1 << 30);
-#elif PCS_MIX_DIAG == 2
-        r.iters = m.n_phase | (m.n_line << 12) | (1 << 30);
-#else
-        r.iters = (int)((clock64() - t0) >> 10) | (1 << 30);
-#endif
-#endif
-        mix_store<DEW>(i, rc, r, T, p_out, rho4, status, iters);
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -272,11 +137,25 @@ __global__ __launch_bounds__(64, MIX_WAVES) void k_mix_bubble_dew_retry(const do
 // rows are first ordered by class (device counting sort -> perm, expensive classes first so their long
 // rows overlap with the bulk), then a fixed set of resident waves works through that order: a lane that
 // finishes its row stores it and takes the next one, every pass of the wave's loop is one evaluation
-// for all its lanes.  No second pass: slow rows just keep their lane longer.
-// control block (int32, after perm[n] in the workspace): [0..8] class counts -> offsets, [16] queue head
+// for all its lanes.
+//
+// Round 3: the solve is cut in two queue kernels at the point where the Newton iteration starts.  Every pass of a
+// queue wave executes the evaluation (1,600-3,500 instructions by class) AND the union of the solver code of all the
+// stages its lanes are in -- liquid-root logic, the substitution sweep (4 exp, 3 log, 8 divisions), the Newton step
+// (3x3 solve, 3 exp, 4 log): with all stages in one kernel that union was nearly as long as the evaluation itself.
+//   k_mix_init_queue   the plain form's initialisation only (liquid roots, Raoult + successive substitution; BdLane in
+//                      INIT mode): ends a row where the Newton would start and writes (rho_spec, rho_inc_1, rho_inc_2)
+//                      + a code to the workspace; rows whose plain initialisation fails at a liquid root are appended to
+//                      the `robust` list, rows that fail otherwise are final;
+//   k_mix_bubble_dew_queue  first the robust list (second attempt from scratch, bracketed liquid roots: the long rows
+//                      start first and overlap with the bulk), then every other row straight into the Newton stage.
+// The arithmetic of a row is the state machine's, stage by stage, as before: same results.
+// control block (int32, after perm[n] in the workspace): [0..8] class counts -> offsets, [16] / [17] queue heads of the
+// two kernels, [18] length of the robust list
 // ------------------------------------------------------------------------------------------
-constexpr int QCTRL_HEAD = 16, QCTRL_INTS = 64;
+constexpr int QCTRL_HEAD = 16, QCTRL_HEAD2 = 17, QCTRL_NROB = 18, QCTRL_INTS = 64;
 constexpr int QCHUNK = 64;  // rows a wave reserves per atomic on the queue head
+enum : int { INIT_OK = 0, INIT_OK_ROOT_FAILED = 1, INIT_FAILED = 2, INIT_ROBUST = 3 };  // code of a row's init record
 
 __device__ __forceinline__ int mix_queue_bin(const double* __restrict__ row) { return MIX_BINS - 1 - mix_bucket(row); }
 
@@ -299,7 +178,6 @@ __global__ void k_mix_class_scan(int32_t* __restrict__ ctrl) {
             ctrl[b] = acc;
             acc += c;
         }
-        ctrl[QCTRL_HEAD] = 0;
     }
 }
 
@@ -320,105 +198,262 @@ __global__ __launch_bounds__(256) void k_mix_class_scatter(const double* __restr
     if (i < n) perm[base[bin] + rank] = (int32_t)i;
 }
 
-// PCS_QUEUE_LDS_COEF = 1: the work-queue kernel keeps each lane's model coefficients in LDS (520 B per lane, 32.5 KB per
-// wave, one wave per SIMD: 130 of the CU's 160 KB).  The evaluation is a non-inlined call (it needs the whole VGPR file), so the coefficients
-// cannot stay in registers across it; handed over by reference they live in private memory and the callee reads them back
-// with ~37 flat loads per call (a memory round trip the single resident wave cannot hide: 24 % of the wave's cycles were
-// SQ_WAIT_ANY).  With the model object in LDS the same flat loads resolve in the LDS aperture.
-// Measured (round 2, 1e6 rows): SQ_WAIT_ANY 8.7e8 -> 6.1e8 quad-cycles per dew launch, but the build then saves the
-// callee-saved VGPRs of the evaluation function through scratch (79 stores + 79 loads per call) and the kernel time does
-// not move (2.92 / 6.64 ms against 2.90 / 6.70 ms): off.
-#ifndef PCS_QUEUE_LDS_COEF
-#define PCS_QUEUE_LDS_COEF 0
-#endif
-// PCS_QUEUE_LDS_STATE = 1: the per-lane solver state (BdLane, 47 doubles) of the work-queue kernel lives in LDS (24 KB per
-// wave) instead of AGPRs: 1,613 -> 453 AGPR moves and 4,427 -> 3,155 VALU instructions in the kernel body, bubble 2.87 -> 2.71 ms,
-// dew 6.43 -> 6.25 ms per 1e6 rows, identical results.  With the state out of the registers two waves per SIMD were tried again
-// (PCS_QUEUE_WAVES_PER_SIMD = 2): the model coefficients and the loop's own values then spill (344 scratch instructions) and LDS
-// holds six waves per CU: 3.56 / 9.86 ms.
-#ifndef PCS_QUEUE_LDS_STATE
-#define PCS_QUEUE_LDS_STATE 1
-#endif
-struct alignas(16) MixModelSlot {
-    MixModel m;
-    double pad[(520 - sizeof(MixModel) % 520) / 8];  // lane stride 520 B = 130 dwords: consecutive lanes two banks apart
+// ------------------------------------------------------------------------------------------
+// K5 pre-pass (dew points): Raoult's law needs the zero-pressure liquid fugacity of both PURE components.  The solver's
+// state machine finds them with the full mixture evaluation at x = (1, 0) and (0, 1) -- 8-9 of a dew row's ~20 T2
+// evaluations, on the one-wave-per-SIMD queue kernel.  At those compositions the mixture model IS the pure-component
+// model (BMCSL -> Carnahan-Starling, g_ii -> (1 - eta/2)/(1 - eta)^3, one-fluid dispersion -> the pure sums, the dipole
+// quotient's pure limit, association of the component's own sites only), so the same Newton iteration -- same start,
+// same scaled function, same acceptance rule, same first-order carry of the chemical potential to the root as
+// BdLane::consume (S_ROOT, plain form) -- runs here on the closed-form pure evaluation (pure_a<double, D2>, ~350
+// instructions instead of 1,600-3,500), one (row, component) per lane, four waves per SIMD.  Results agree with the
+// state machine's to rounding; a lane the plain form would give up on writes NaN and the row takes the state machine's own
+// route (including its robust second attempt), so no decision of the solver changes.
+// fug[2 k + c] = rho_L exp(mu_res) of component c of the row at queue position k at p = 0, or NaN.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mix_pure_fugacity(const double* __restrict__ params, const double* __restrict__ temp,
+                                                           int64_t n, const int32_t* __restrict__ perm,
+                                                           double* __restrict__ fug) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < 2 * n;
+    const int64_t pos = live ? (t >> 1) : 0;
+    const int comp = (int)(t & 1);
+    int64_t row = perm ? perm[pos] : pos;
+    if (row < 0 || row >= n) row = 0;
+    double par[8], oth[8];
+    {
+        const double2* src = reinterpret_cast<const double2*>(params + 16 * row + 8 * comp);
+        const double2* so = reinterpret_cast<const double2*>(params + 16 * row + 8 * (1 - comp));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double2 v = src[k], w = so[k];
+            par[2 * k] = v.x; par[2 * k + 1] = v.y;
+            oth[2 * k] = w.x; oth[2 * k + 1] = w.y;
+        }
+    }
+    const double T = temp[row];
+    // the component's own association in the pure limit: only a self-associating component associates with itself.  In the
+    // class with ONE associating component the reference sums kappa and eps over both components (pcsaft_mix.py:211-218):
+    // the pure model is that limit only if the site-less partner carries none
+    const bool self_i = par[6] * par[7] != 0.0;
+    const bool other_sites = oth[6] + oth[7] != 0.0;
+    bool usable = !(self_i && !other_sites && (oth[4] != 0.0 || oth[5] != 0.0));
+    if (!self_i) { par[6] = 0.0; par[7] = 0.0; }
+    PureCoef<double> c;
+    pure_coef<double>(c, par, T, false);
+    const double pk = c.ceta;
+    double rho = 0.5 / pk, err_prev = 1.0, f = __longlong_as_double(0x7ff8000000000000LL);
+    bool dense = false, active = live && usable;
+    int it = 0;
+    for (int guard = 0; guard < LIQ_ROOT_MAX_IT + 2; guard++) {
+        if (active) {
+            const D2<double> a = pure_a<double, D2<double>>(c, D2<double>(rho, 1.0, 0.0));
+            const double p = rho - a.v + rho * a.d1, dp = 1.0 + rho * a.d2;
+            if (it == 0 && !dense && !(p > 0.0)) {
+                rho = 0.62 / pk;  // very cold / dense: restart on the dense side (BdLane::consume)
+                dense = true;
+            } else {
+                const double den = dense ? dp : dp - 4.0 * p * pk / (1.0 - rho * pk);
+                bool bad = !(dp > 0.0) || !(den > 0.0) || !is_finite_bits(p);
+                const double step = p / den, rho_new = rho - step;
+                bad = bad || !(rho_new > 0.0) || !is_finite_bits(rho_new);
+                bad = bad || (dense && !(rho_new * pk > 0.5 && rho_new * pk < 0.62));
+                bool done = false;
+                if (!bad) {
+                    const double err = fabs(step) / rho;
+                    done = err <= LIQ_ROOT_TOL || (it >= 3 && err < 1e-7 && err >= 0.25 * err_prev);
+                    err_prev = err;
+                    it++;
+                    if (!done && it >= LIQ_ROOT_MAX_IT) bad = true;
+                }
+                if (bad) {
+                    active = false;  // NaN: the state machine decides (robust second attempt)
+                } else if (done) {
+                    f = rho_new * exp(a.d1 - a.d2 * step);  // chemical potential carried to the root to first order
+                    active = false;
+                } else {
+                    rho = rho_new;
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) break;
+    }
+    if (live) fug[2 * pos + comp] = f;
+}
+
+// One wave's slice of a queue [0, total): hands `rank`-th idle lane the queue position next + rank.  Wave-uniform state.
+struct QueueSlice {
+    int next = 0, end = 0;
+    bool drained = false;
+    // reserves a new chunk when the slice is empty; false when the queue is exhausted
+    __device__ __forceinline__ bool refill(int32_t* __restrict__ head, int total) {
+        if (next < end) return true;
+        if (drained) return false;
+        int h = 0;
+        if ((threadIdx.x & 63) == 0) h = atomicAdd(head, QCHUNK);
+        h = __builtin_amdgcn_readfirstlane(h);
+        if (h >= total) { drained = true; next = end = 0; return false; }
+        next = h;
+        end = h + QCHUNK < total ? h + QCHUNK : total;
+        return true;
+    }
 };
 
+// the per-lane solver state of a queue kernel lives in LDS (24 KB per wave, padded to an odd number of doubles per lane):
+// 1,613 -> 453 AGPR moves in the kernel body, -5 % / -3 % kernel time (round 2)
+template <class Lane>
+struct alignas(8) LaneSlot {
+    Lane L;
+    double pad[(sizeof(Lane) / 8) % 2 == 0 ? 1 : 2];
+};
+
+// What a queue lane loads when it takes a row.  (Round 3 also tried to set the coefficients up ONCE per row in a separate
+// kernel and to hand the queue lanes a 544-byte record: the refill then waits for 34 scattered 16-byte loads with nothing to
+// hide the latency behind -- one wave per SIMD -- and the solve got slower, bubble 2.6 -> 3.1 ms, dew 5.2 -> 5.5 ms per 1e6
+// rows; with the evaluation reading the record in place, uncoalesced, 3.6 / 5.9 ms.  The set-up stays in the refill.)
+struct RowScalars {
+    int64_t row;
+    double T, z, p_red;
+};
+__device__ __forceinline__ RowScalars take_row(const double* __restrict__ params, const double* __restrict__ kij,
+                                               const double* __restrict__ temp, const double* __restrict__ z,
+                                               const double* __restrict__ p_init, int64_t row, MixModel& m) {
+    double par[16], k0, k1;
+    load_mix_row(params, kij, row, par, k0, k1);
+    RowScalars r;
+    r.row = row;
+    r.T = temp[row];
+    r.z = z[row];
+    r.p_red = p_init[row] / (r.T * P_UNIT);
+    mix_coef<double>(m.c, par, k0, k1, r.T);
+    return r;
+}
+
+// K5a: initialisation of the plain form (see above).  init[k] = (rho_spec, rho_inc_1, rho_inc_2, code) of queue position k
 template <bool DEW>
-__global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew_queue(const double* __restrict__ params,
+__global__ __launch_bounds__(64, 1) void k_mix_init_queue(const double* __restrict__ params, const double* __restrict__ kij,
+                                                       const double* __restrict__ temp, const double* __restrict__ z,
+                                                       const double* __restrict__ p_init, int64_t n,
+                                                       const int32_t* __restrict__ perm, int32_t* __restrict__ ctrl,
+                                                       const double* __restrict__ fug, double4* __restrict__ init,
+                                                       int32_t* __restrict__ robust_list) {
+    typedef BdLane<DEW, BD_MODE_INIT> Lane;
+    __shared__ LaneSlot<Lane> lane_slots[64];
+    Lane& L = lane_slots[threadIdx.x].L;
+    const int lane = threadIdx.x;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int total = (int)n;
+    QueueSlice q;
+    L.idle();
+    MixModel m;
+    int pos = 0;
+    int evals = 0;  // evaluations of this lane's current row (bounded by BD_EVAL_GUARD: the loop below cannot hang)
+    for (;;) {
+        unsigned long long need = __ballot(L.done());
+        if (__popcll(need) < REFILL_MIN) need = 0ull;
+        while (need != 0ull && q.refill(&ctrl[QCTRL_HEAD], total)) {
+            const int avail = q.end - q.next;
+            const int rank = __popcll(need & below);
+            if (L.done() && ((need >> lane) & 1ull) && rank < avail) {
+                pos = q.next + rank;
+                const RowScalars r = take_row(params, kij, temp, z, p_init, perm[pos], m);
+                double f0 = -1.0, f1 = -1.0;
+                if (DEW && fug) {
+                    const double2 ff = reinterpret_cast<const double2*>(fug)[pos];  // k_mix_pure_fugacity; NaN = not pre-solved
+                    f0 = ff.x;
+                    f1 = ff.y;
+                }
+                L.start(m, r.z, r.p_red, SS_MAX_IT, NEWTON_MAX_IT, false, f0, f1);
+                evals = 0;
+            }
+            const int wanted = __popcll(need);
+            q.next += wanted < avail ? wanted : avail;
+            need = __ballot(L.done());
+        }
+        if (__ballot(!L.done()) == 0ull) break;  // nothing in flight and nothing left to take
+        if (!L.done()) {
+            double e0, e1;
+            L.point(e0, e1);
+            PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
+            L.consume(m, e);
+            if (++evals >= BD_EVAL_GUARD && !L.done()) L.idle();  // rc = BD_FAILED
+            if (L.done()) {
+                int code = INIT_FAILED;
+                if (L.rc == BD_HANDOVER) code = L.root_failed ? INIT_OK_ROOT_FAILED : INIT_OK;
+                else if (L.root_failed) {
+                    // the plain form gave the row up at a liquid root: second attempt with bracketed liquid roots, from
+                    // scratch, at the head of the second kernel's queue.  Rows that fail with sound roots are not repeated
+                    // (the robust form differs in the roots only)
+                    code = INIT_ROBUST;
+                    const int slot = atomicAdd(&ctrl[QCTRL_NROB], 1);
+                    if (slot >= 0 && slot < total) robust_list[slot] = pos;
+                }
+                init[pos] = make_double4(L.out.spec0, L.out.inc0, L.out.inc1, (double)code);
+            }
+        }
+    }
+}
+
+// K5b: robust list first, then the Newton iteration of every initialised row
+template <bool DEW>
+__global__ __launch_bounds__(64, 1) void k_mix_bubble_dew_queue(const double* __restrict__ params,
                                                              const double* __restrict__ kij,
                                                              const double* __restrict__ temp,
                                                              const double* __restrict__ z,
                                                              const double* __restrict__ p_init, int64_t n,
                                                              const int32_t* __restrict__ perm, int32_t* __restrict__ ctrl,
+                                                             const double4* __restrict__ init,
+                                                             const int32_t* __restrict__ robust_list,
                                                              double* __restrict__ p_out, double* __restrict__ rho4,
                                                              uint8_t* __restrict__ status, int32_t* __restrict__ iters) {
-#if PCS_QUEUE_LDS_COEF
-    __shared__ MixModelSlot slots[64];
-#endif
+    typedef BdLane<DEW, BD_MODE_FULL> Lane;
+    __shared__ LaneSlot<Lane> lane_slots[64];
+    Lane& L = lane_slots[threadIdx.x].L;
     const int lane = threadIdx.x;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int total = (int)n;
-    int next = 0, end = 0;  // this wave's reserved slice [next, end) of the queue (wave-uniform)
-    bool drained = false;   // queue head passed n (wave-uniform)
-#if PCS_QUEUE_LDS_STATE
-    // the solver state of every lane in LDS (padded to an odd number of doubles per lane): nothing of it is live in
-    // registers across the evaluation call, so the kernel fits the 256 registers of two waves per SIMD
-    struct alignas(8) LaneSlot {
-        BdLane<DEW> L;
-        double pad[(sizeof(BdLane<DEW>) / 8) % 2 == 0 ? 1 : 2];
-    };
-    __shared__ LaneSlot lane_slots[64];
-    BdLane<DEW>& L = lane_slots[threadIdx.x].L;
-#else
-    BdLane<DEW> L;
-#endif
+    const int n_rob = min(max(ctrl[QCTRL_NROB], 0), (int)n);
+    const int total = (int)n + n_rob;
+    QueueSlice q;
     L.idle();
-#if PCS_QUEUE_LDS_COEF
-    MixModel& m = slots[threadIdx.x].m;
-#else
     MixModel m;
-#endif
-    int64_t row = -1;
-    double T = 0.0;
-    int evals = 0;  // evaluations of this lane's current row (bounded by BD_EVAL_GUARD: the loop below cannot hang)
-#if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
-    int nev = 0, t_start = 0;  // diagnostics: evaluations of this lane's row, kernel-relative start time
-    const long long t_kernel = clock64();
-#endif
+    RowScalars r;
+    r.row = 0; r.T = r.z = r.p_red = 0.0;
+    int evals = 0;
     for (;;) {
         // hand rows to the lanes that have none
         unsigned long long need = __ballot(L.done());
-#if PCS_REFILL_MIN > 1
-        if (__popcll(need) < PCS_REFILL_MIN) need = 0ull;  // wait until a few lanes are free: the refill code runs for the whole wave
-#endif
-        while (need != 0ull && !(drained && next >= end)) {
-            if (next >= end) {
-                int head = 0;
-                if (lane == 0) head = atomicAdd(&ctrl[QCTRL_HEAD], QCHUNK);
-                head = __builtin_amdgcn_readfirstlane(head);
-                next = head;
-                end = head + QCHUNK < total ? head + QCHUNK : total;
-                if (head >= total) { drained = true; next = end = 0; break; }
-            }
-            const int avail = end - next;
+        if (__popcll(need) < REFILL_MIN) need = 0ull;  // wait until a few lanes are free: the refill code runs for the whole wave
+        while (need != 0ull && q.refill(&ctrl[QCTRL_HEAD2], total)) {
+            const int avail = q.end - q.next;
             const int rank = __popcll(need & below);
-            const bool take = L.done() && ((need >> lane) & 1ull) && rank < avail;
-            if (take) {
-                row = perm[next + rank];
-                double par[16], k0, k1;
-                load_mix_row(params, kij, row, par, k0, k1);
-                T = temp[row];
-                mix_coef<double>(m.c, par, k0, k1, T);
-                L.start(m, z[row], p_init[row] / (T * P_UNIT));
-                evals = 0;
-#if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
-                nev = 0;
-                t_start = (int)((clock64() - t_kernel) >> 14);
-#endif
+            if (L.done() && ((need >> lane) & 1ull) && rank < avail) {
+                const int qpos = q.next + rank;
+                int pos, code;
+                if (qpos < n_rob) {
+                    pos = robust_list[qpos];
+                    code = (pos >= 0 && pos < (int)n) ? INIT_ROBUST : -1;
+                } else {
+                    pos = qpos - n_rob;
+                    code = (int)init[pos].w;
+                    if (code == INIT_ROBUST) code = -1;  // taken from the robust list
+                }
+                if (code == INIT_FAILED) {
+                    const int64_t row = perm[pos];
+                    L.idle();  // rc = BD_FAILED, final
+                    mix_store<DEW>(row, BD_FAILED, L.out, temp[row], p_out, rho4, status, iters);
+                } else if (code >= 0) {
+                    r = take_row(params, kij, temp, z, p_init, perm[pos], m);
+                    if (code == INIT_ROBUST) {
+                        L.start(m, r.z, r.p_red, SS_MAX_IT, NEWTON_MAX_IT, true);
+                    } else {
+                        const double4 s0 = init[pos];
+                        L.start_newton(r.z, r.p_red, s0.x, s0.y, s0.z, code == INIT_OK_ROOT_FAILED);
+                    }
+                    evals = 0;
+                }
             }
             const int wanted = __popcll(need);
-            next += wanted < avail ? wanted : avail;
+            q.next += wanted < avail ? wanted : avail;
             need = __ballot(L.done());
         }
         if (__ballot(!L.done()) == 0ull) break;  // nothing in flight and nothing left to take
@@ -429,25 +464,20 @@ __global__ __launch_bounds__(64, PCS_QUEUE_WAVES_PER_SIMD) void k_mix_bubble_dew
             L.consume(m, e);
             // evaluation budget: BD_EVAL_GUARD bounds the plain form, robust_eval_budget the second attempt (mix_solver_sm.hpp)
             if (++evals >= (L.robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD) && !L.done()) L.idle();  // rc = BD_FAILED
-#if defined(PCS_MIX_DIAG) && PCS_MIX_DIAG == 2
-            nev++;
-            if (L.done()) L.out.iters = (nev & 4095) | ((t_start & 0xffff) << 12);
-#endif
-            if (PCS_INPLACE_ROBUST && L.done() && L.rc != BD_OK && !L.robust && L.root_failed) {
-                // the plain form gave the row up at a liquid root: second attempt with bracketed liquid roots, in place (the
-                // lane keeps the row and its coefficients; the other lanes of the wave go on with theirs).  Rows that fail in
-                // the Newton with sound roots (98 % of the failing bubble rows: unstable liquids) are not repeated: the
-                // robust form differs in the roots only, and every repeated row is a potential tail of the kernel
-                L.start(m, z[row], p_init[row] / (T * P_UNIT), SS_MAX_IT, NEWTON_MAX_IT, true);
+            if (L.done() && L.rc != BD_OK && !L.robust && L.root_failed) {
+                // a liquid root of the plain form had failed (the row went on with its second choice of the pressure) and the
+                // Newton gave the row up: second attempt with bracketed liquid roots, in place (the lane keeps the row and its
+                // coefficients; the other lanes of the wave go on with theirs)
+                L.start(m, r.z, r.p_red, SS_MAX_IT, NEWTON_MAX_IT, true);
                 evals = 0;
             }
-            if (L.done()) mix_store<DEW>(row, L.rc, L.out, T, p_out, rho4, status, iters);
+            if (L.done()) mix_store<DEW>(r.row, L.rc, L.out, r.T, p_out, rho4, status, iters);
         }
     }
 }
 
 // PcSaftMix.derivatives (feos_torch/pcsaft_mix.py:395-420): a, p, mu_i, v_i at given partial densities
-__global__ __launch_bounds__(MBLOCK, 2) void k_mix_derivatives(const double* __restrict__ params,
+__global__ __launch_bounds__(MBLOCK, 1) void k_mix_derivatives(const double* __restrict__ params,
                                                             const double* __restrict__ kij,
                                                             const double* __restrict__ temp,
                                                             const double* __restrict__ rho, int64_t n,
@@ -547,6 +577,9 @@ __global__ __launch_bounds__(64) void k_mix_derivatives_vjp(const double* __rest
                         grad + MIX_VJP_DIRS * i);
 }
 
+// byte offset / pointer of the pre-pass area behind perm[n] + control block in the mixture workspace
+int64_t mix_ws_offset(int64_t n) { return (((int64_t)sizeof(int32_t) * ((n > 0 ? n : 0) + QCTRL_INTS)) + 15) & ~(int64_t)15; }
+
 // resident waves of the queue kernel: one per SIMD (the evaluation needs the whole register file)
 int queue_waves() {
     static int waves = 0;
@@ -554,7 +587,7 @@ int queue_waves() {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        waves = cus * 4 * PCS_QUEUE_WAVES_PER_SIMD;
+        waves = cus * 4;
     }
     return waves;
 }
@@ -563,6 +596,13 @@ int queue_waves() {
 
 extern "C" {
 
+// workspace of pcs_mix_bubble_dew: row order perm[n] + control block (as pcs_workspace_bytes), then -- 16-byte aligned --
+// the pre-pass fugacities (2 doubles per row), the init records (4 doubles per row) and the robust list (1 int per row)
+int64_t pcs_mix_workspace_bytes(int64_t n) {
+    const int64_t m = n > 0 ? n : 0;
+    return mix_ws_offset(n) + (int64_t)sizeof(double) * 6 * m + (int64_t)sizeof(int32_t) * m;
+}
+
 int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const double* temp, const double* z,
                        const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status, int32_t* iters,
                        void* workspace, void* stream) {
@@ -570,50 +610,49 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
     if (int e = check_n(n)) return e;
     if (n == 0) return 0;
     if (!params || !kij || !temp || !z || !p_init || !status) return fail_msg("pcs_mix_bubble_dew: null required pointer");
-    const unsigned grid = (unsigned)((n + MBLOCK - 1) / MBLOCK);
     hipStream_t s = as_stream(stream);
-#if PCS_MIX_QUEUE
     if (workspace) {
-        // work-queue schedule: perm[n] + control block in the workspace
+        // work-queue schedule: perm[n] + control block, pre-pass fugacities, init records and the robust list in the workspace
         int32_t* perm = static_cast<int32_t*>(workspace);
         int32_t* ctrl = perm + n;
+        double* fug = reinterpret_cast<double*>(static_cast<char*>(workspace) + mix_ws_offset(n));
+        double4* init = reinterpret_cast<double4*>(fug + 2 * n);
+        int32_t* robust_list = reinterpret_cast<int32_t*>(fug + 6 * n);
         if (int ez = zero_ints(ctrl, QCTRL_INTS, s)) return ez;
         const unsigned g256 = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);
         hipLaunchKernelGGL(k_mix_class_scan, dim3(1), dim3(64), 0, s, ctrl);
         hipLaunchKernelGGL(k_mix_class_scatter, dim3(g256), dim3(256), 0, s, params, n, ctrl, perm);
-        hipError_t e;
+        if (dew)
+            hipLaunchKernelGGL(k_mix_pure_fugacity, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, s, params, temp, n,
+                               (const int32_t*)perm, fug);
         unsigned waves = (unsigned)queue_waves();
         const unsigned needed = (unsigned)((n + 63) / 64);
         if (waves > needed) waves = needed;
-        if (dew)
+        if (dew) {
+            hipLaunchKernelGGL(k_mix_init_queue<true>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
+                               (const int32_t*)perm, ctrl, (const double*)fug, init, robust_list);
             hipLaunchKernelGGL(k_mix_bubble_dew_queue<true>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
-                               (const int32_t*)perm, ctrl, p_out, rho4, status, iters);
-        else
+                               (const int32_t*)perm, ctrl, (const double4*)init, (const int32_t*)robust_list, p_out, rho4, status,
+                               iters);
+        } else {
+            hipLaunchKernelGGL(k_mix_init_queue<false>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
+                               (const int32_t*)perm, ctrl, (const double*)nullptr, init, robust_list);
             hipLaunchKernelGGL(k_mix_bubble_dew_queue<false>, dim3(waves), dim3(64), 0, s, params, kij, temp, z, p_init, n,
-                               (const int32_t*)perm, ctrl, p_out, rho4, status, iters);
-        e = hipGetLastError();
+                               (const int32_t*)perm, ctrl, (const double4*)init, (const int32_t*)robust_list, p_out, rho4, status,
+                               iters);
+        }
+        hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail("k_mix_bubble_dew_queue launch", e);
         return 0;
     }
-#endif
-    int32_t* retry = static_cast<int32_t*>(workspace);
-    if (retry) {
-        if (int ez = zero_ints(retry, 1, s)) return ez;
-    }
-    if (dew) {
-        hipLaunchKernelGGL(k_mix_bubble_dew<true>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
-                           rho4, status, iters, retry);
-        if (retry)
-            hipLaunchKernelGGL(k_mix_bubble_dew_retry<true>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
-                               p_out, rho4, status, iters, (const int32_t*)retry, n);
-    } else {
-        hipLaunchKernelGGL(k_mix_bubble_dew<false>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out,
-                           rho4, status, iters, retry);
-        if (retry)
-            hipLaunchKernelGGL(k_mix_bubble_dew_retry<false>, dim3(MIX_RETRY_GRID), dim3(64), 0, s, params, kij, temp, z, p_init,
-                               p_out, rho4, status, iters, (const int32_t*)retry, n);
-    }
+    const unsigned grid = (unsigned)((n + MBLOCK - 1) / MBLOCK);
+    if (dew)
+        hipLaunchKernelGGL(k_mix_bubble_dew<true>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out, rho4,
+                           status, iters);
+    else
+        hipLaunchKernelGGL(k_mix_bubble_dew<false>, dim3(grid), dim3(MBLOCK), 0, s, params, kij, temp, z, p_init, n, p_out, rho4,
+                           status, iters);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_mix_bubble_dew launch", e);
     return 0;

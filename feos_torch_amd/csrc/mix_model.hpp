@@ -274,39 +274,26 @@ PCS_DEV void induced_refine(T2<T>& xa, const T2<T>& na0, const T2<T>& na1, const
     xa = xa - dx;
 }
 
-// Packing-fraction quantities shared by all contributions
-template <class R>
+// Packing-fraction quantities shared by all contributions.  Z: type of zeta_3 and of everything that depends on it alone --
+// R in general; D2<double> where the caller evaluates in the coordinates (zeta_3, rho_2) (dual.hpp, "D2 (x) T2")
+template <class R, class Z = R>
 struct Packing {
-    R zeta2, zeta3, z3m1, z3m2, omz;
+    R zeta2;
+    Z zeta3, z3m1, z3m2, omz;
 };
-
-// PCS_CONST_MEM: the 42 universal dispersion constants from constant memory (s_load_dwordx8/x16, a few scalar loads per
-// evaluation) instead of instruction literals (two s_mov_b32 per constant per use: 18 SALU per 100 VALU instructions in the
-// evaluation function, and with one wave per SIMD every scalar instruction costs an issue slot of that wave).
-#ifndef PCS_CONST_MEM
-#define PCS_CONST_MEM 0
-#endif
-#if PCS_CONST_MEM
-#define PCS_ROW7(X) {X[0], X[1], X[2], X[3], X[4], X[5], X[6]}
-alignas(64) static __constant__ double DISP_CM[6][7] = {PCS_ROW7(A0), PCS_ROW7(A1), PCS_ROW7(A2), PCS_ROW7(B0), PCS_ROW7(B1), PCS_ROW7(B2)};
-#define PCS_K(i, X) (disp_k + 7 * (i))
-#else
-#define PCS_K(i, X) X
-#endif
 
 // hard sphere (:56-60) + dispersion (:69-106) + dipoles (:156-208) for any coefficient struct C that
 // provides m[2], zk[4][2], A[3], B[3], polar, pj, tj (MixCoef, GcCoef).  Fills `pk`.
-template <class C, class R>
-PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
+template <class C, class R, class Z>
+PCS_DEV R core_terms_z(const C& c, const R& r0, const R& r1, const Z& zeta3, Packing<R, Z>& pk) {
     R zeta0 = r0 * c.zk[0][0] + r1 * c.zk[0][1];
     R zeta1 = r0 * c.zk[1][0] + r1 * c.zk[1][1];
     R zeta2 = r0 * c.zk[2][0] + r1 * c.zk[2][1];
-    R zeta3 = r0 * c.zk[3][0] + r1 * c.zk[3][1];
-    R omz = 1.0 - zeta3;
-    R z3m1 = d_recip(omz);
-    R z3m2 = z3m1 * z3m1;
+    Z omz = 1.0 - zeta3;
+    Z z3m1 = d_recip(omz);
+    Z z3m2 = z3m1 * z3m1;
     R zeta23 = zeta2 * d_recip(zeta3);
-    R l13 = d_log(omz);
+    Z l13 = d_log(omz);
     pk.zeta2 = zeta2; pk.zeta3 = zeta3; pk.z3m1 = z3m1; pk.z3m2 = z3m2; pk.omz = omz;
 
     // hard sphere
@@ -319,15 +306,11 @@ PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
     R rmb = d_recip(mbar);
     R m1 = (mbar - 1.0) * rmb;
     R m2 = m1 * ((mbar - 2.0) * rmb);
-#if PCS_CONST_MEM
-    const double* disp_k = &DISP_CM[0][0];
-    asm volatile("" : "+s"(disp_k));  // opaque: the initialiser is not folded back into literals
-#endif
-    R I1 = horner_zeta<7>(PCS_K(0, A0), zeta3) + m1 * horner_zeta<7>(PCS_K(1, A1), zeta3) + m2 * horner_zeta<7>(PCS_K(2, A2), zeta3);
-    R I2 = horner_zeta<7>(PCS_K(3, B0), zeta3) + m1 * horner_zeta<7>(PCS_K(4, B1), zeta3) + m2 * horner_zeta<7>(PCS_K(5, B2), zeta3);
-    R z3m4 = z3m2 * z3m2;
-    R t2 = z3m1 * d_recip(2.0 - zeta3);
-    R poly = zeta3 * (20.0 + zeta3 * (-27.0 + zeta3 * (12.0 - 2.0 * zeta3)));
+    R I1 = horner_z<7>(A0, zeta3) + m1 * horner_z<7>(A1, zeta3) + m2 * horner_z<7>(A2, zeta3);
+    R I2 = horner_z<7>(B0, zeta3) + m1 * horner_z<7>(B1, zeta3) + m2 * horner_z<7>(B2, zeta3);
+    Z z3m4 = z3m2 * z3m2;
+    Z t2 = z3m1 * d_recip(2.0 - zeta3);
+    Z poly = zeta3 * (20.0 + zeta3 * (-27.0 + zeta3 * (12.0 - 2.0 * zeta3)));
     R C1 = d_recip(1.0 + mbar * ((zeta3 * (8.0 - 2.0 * zeta3)) * z3m4) + (1.0 - mbar) * (poly * (t2 * t2)));
     R rho1mix = r00 * c.A[0] + r01 * c.A[1] + r11 * c.A[2];
     R rho2mix = r00 * c.B[0] + r01 * c.B[1] + r11 * c.B[2];
@@ -335,15 +318,19 @@ PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
 
     // dipoles
     if (c.polar) {
-        R phi2 = r00 * horner_zeta<5>(c.pj[0], zeta3) + r01 * horner_zeta<5>(c.pj[1], zeta3) + r11 * horner_zeta<5>(c.pj[2], zeta3);
-        R phi3 = (r00 * r0) * horner_zeta<4>(c.tj[0], zeta3) + (r00 * r1) * horner_zeta<4>(c.tj[1], zeta3) +
-                 (r0 * r11) * horner_zeta<4>(c.tj[2], zeta3) + (r11 * r1) * horner_zeta<4>(c.tj[3], zeta3);
+        R phi2 = r00 * horner_z<5>(c.pj[0], zeta3) + r01 * horner_z<5>(c.pj[1], zeta3) + r11 * horner_z<5>(c.pj[2], zeta3);
+        R phi3 = (r00 * r0) * horner_z<4>(c.tj[0], zeta3) + (r00 * r1) * horner_z<4>(c.tj[1], zeta3) +
+                 (r0 * r11) * horner_z<4>(c.tj[2], zeta3) + (r11 * r1) * horner_z<4>(c.tj[3], zeta3);
         // phi2 = phi3 = 0 where no polar component is present (pure-component limit next to a polar partner): the
         // quotient's limit is phi2 + O(rho_polar^3) (value and gradient 0, Hessian that of phi2)
         if (re(phi2) == 0.0) a = a + phi2;
         else a = a + (phi2 * phi2) * d_recip(phi2 - phi3);
     }
     return a;
+}
+template <class C, class R>
+PCS_DEV R core_terms(const C& c, const R& r0, const R& r1, Packing<R>& pk) {
+    return core_terms_z<C, R, R>(c, r0, r1, r0 * c.zk[3][0] + r1 * c.zk[3][1], pk);
 }
 
 // The dispersion term is linear in the aggregates: a_disp = F1 (r00 A0 + r01 A1 + r11 A2) + F2 (r00 B0 + r01 B1 + r11 B2)
@@ -369,12 +356,13 @@ PCS_DEV void dispersion_factors(const C& c, const R& r0, const R& r1, R& F1, R& 
     F2 = (-PI) * ((C1 * I2) * mbar);
 }
 
-// stage 2: a(rho_0, rho_1) at fixed coefficients
-template <class P, class R>
-PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
-    Packing<R> pk;
-    R a = core_terms(c, r0, r1, pk);
-    const R &zeta2 = pk.zeta2, &z3m1 = pk.z3m1;
+// stage 2: a(rho_0, rho_1) at fixed coefficients; zeta3 = the packing fraction as Z (see Packing)
+template <class P, class R, class Z>
+PCS_DEV R mix_a_z(const MixCoef<P>& c, const R& r0, const R& r1, const Z& zeta3) {
+    Packing<R, Z> pk;
+    R a = core_terms_z<MixCoef<P>, R, Z>(c, r0, r1, zeta3, pk);
+    const R& zeta2 = pk.zeta2;
+    const Z& z3m1 = pk.z3m1;
 
     // hard chain (:63-65):  g_i = 1/(1-z3) + 1.5 d_i c + 0.5 d_i^2 c^2 (1 - z3),  c = z2/(1-z3)^2
     R cc = zeta2 * pk.z3m2;
@@ -478,6 +466,10 @@ PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
         }
     }
     return a;
+}
+template <class P, class R>
+PCS_DEV R mix_a(const MixCoef<P>& c, const R& r0, const R& r1) {
+    return mix_a_z<P, R, R>(c, r0, r1, r0 * c.zk[3][0] + r1 * c.zk[3][1]);
 }
 
 }  // namespace pcs

@@ -41,13 +41,34 @@ struct PhaseEval {
 #ifndef PCS_EVAL_ATTR
 #define PCS_EVAL_ATTR __device__ __attribute__((noinline))
 #endif
+// Value, gradient and Hessian of a in the partial densities.  Evaluated in the coordinates (u, w) = (zeta_3, rho_2) -- the
+// packing fraction zeta_3 = c0 rho_1 + c1 rho_2 (c_i = packing(e_i) > 0) is a linear, invertible change of the first
+// coordinate -- so that every function of the packing fraction alone is a one-variable Taylor series (dual.hpp, "D2 (x)
+// T2"), then mapped back:  d/drho_1 = c0 d/du,  d/drho_2 = c1 d/du + d/dw.
 template <class Model>
 PCS_DEV PhaseEval phase_eval_inline(const Model& m, double r0, double r1) {
     typedef T2<double> R;
-    R a = m.template a<R>(R(r0, 1.0, 0.0, 0.0, 0.0, 0.0), R(r1, 0.0, 1.0, 0.0, 0.0, 0.0));
+#ifdef PCS_EVAL_PLAIN  // A/B builds: both partial densities as coordinates
+    {
+        R a = m.template a<R>(R(r0, 1.0, 0.0, 0.0, 0.0, 0.0), R(r1, 0.0, 1.0, 0.0, 0.0, 0.0));
+        PhaseEval e;
+        e.r0 = r0; e.r1 = r1;
+        e.a = a.v; e.g0 = a.g0; e.g1 = a.g1; e.h00 = a.h00; e.h01 = a.h01; e.h11 = a.h11;
+        return e;
+    }
+#endif
+    typedef D2<double> Z;
+    const double c0 = m.packing(1.0, 0.0), c1 = m.packing(0.0, 1.0);
+    const double rc0 = 1.0 / c0;
+    R a = m.template a_z<R, Z>(R(r0, rc0, -(c1 * rc0), 0.0, 0.0, 0.0), R(r1, 0.0, 1.0, 0.0, 0.0, 0.0), Z(r0 * c0 + r1 * c1, 1.0, 0.0));
     PhaseEval e;
     e.r0 = r0; e.r1 = r1;
-    e.a = a.v; e.g0 = a.g0; e.g1 = a.g1; e.h00 = a.h00; e.h01 = a.h01; e.h11 = a.h11;
+    e.a = a.v;
+    e.g0 = c0 * a.g0;
+    e.g1 = c1 * a.g0 + a.g1;
+    e.h00 = (c0 * c0) * a.h00;
+    e.h01 = c0 * (c1 * a.h00 + a.h01);
+    e.h11 = c1 * (c1 * a.h00 + 2.0 * a.h01) + a.h11;
     return e;
 }
 template <class Model>

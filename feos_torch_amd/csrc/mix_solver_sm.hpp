@@ -45,7 +45,14 @@ template <bool DEW> constexpr int robust_eval_budget() { return DEW ? PCS_ROBUST
 // independent continuation solver (oracle/mix_continuation.hpp, tests/test_mix_missed_gpu.py): of the rows the first pass
 // fails on, the ones that do have a solution are recovered by this pass.  A bubble-point row whose specified liquid is
 // diffusionally unstable at its root (inside a liquid-liquid spinodal: 98 % of the rows that fail) is given up at once.
-template <bool DEW>
+// MODE: BD_MODE_FULL -- the whole solve; BD_MODE_INIT -- the plain form's initialisation only: where the Newton iteration
+// would start the lane is done with rc = BD_HANDOVER and (rho_spec, rho_inc_1, rho_inc_2) in out.spec0 / inc0 / inc1, to be
+// continued by a FULL lane through start_newton() (the two work-queue kernels of mix_kernels.hip).  The robust branches and
+// the Newton stages are compiled out of an INIT lane.
+enum : int { BD_MODE_FULL = 0, BD_MODE_INIT = 1 };
+constexpr int BD_HANDOVER = 3;  // return code of an INIT lane (next to BD_OK / BD_FAILED / BD_CAP)
+
+template <bool DEW, int MODE = BD_MODE_FULL>
 struct BdLane {
     bool robust;
     bool root_failed;  // a cold liquid root of this attempt failed: the only kind of failure the robust form can repair
@@ -96,7 +103,7 @@ struct BdLane {
 
     template <class Model>
     PCS_DEV void start(const Model& m, double z0_, double p_init_, int ss_max_ = SS_MAX_IT, int newton_max_ = NEWTON_MAX_IT,
-                       bool robust_ = false) {
+                       bool robust_ = false, double fug0 = -1.0, double fug1 = -1.0) {
         robust = robust_;
         root_failed = false;
         z0 = z0_; z1 = 1.0 - z0_; p_init = p_init_;
@@ -110,8 +117,40 @@ struct BdLane {
         sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
         out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
         out.iters = 0;
-        if (DEW) start_root(m, R_PURE0, 1.0, 0.0, 0.0, false, 0.0);
+        if (DEW && !robust_ && fug0 > 0.0 && fug1 > 0.0 && is_finite_bits(fug0) && is_finite_bits(fug1)) {
+            // pure-liquid fugacities from the pre-pass (k_mix_pure_fugacity: the same two roots on the pure-component
+            // evaluation): straight to Raoult's law, as after R_PURE1 below
+            f0 = fug0;
+            p0 = 1.0 / (z0 / fug0 + z1 / fug1);
+            x0 = z0 * p0 / fug0;
+            x1 = z1 * p0 / fug1;
+            start_root(m, R_SS, x0, x1, 0.0, true, p0);
+        } else if (DEW) start_root(m, R_PURE0, 1.0, 0.0, 0.0, false, 0.0);
         else start_root(m, R_BUBBLE, z0, z1, p_init, true, 0.0);
+    }
+
+    // continue a row an INIT lane has initialised: the Newton iteration from (rho_spec, rho_inc_1, rho_inc_2);
+    // root_failed_ = a liquid root of that initialisation had failed (decides whether a failing Newton is followed by the
+    // robust second attempt)
+    PCS_DEV void start_newton(double z0_, double p_init_, double rs_, double ri0_, double ri1_, bool root_failed_) {
+        robust = false;
+        root_failed = root_failed_;
+        z0 = z0_; z1 = 1.0 - z0_; p_init = p_init_;
+        ss_max = SS_MAX_IT; newton_max = NEWTON_MAX_IT;
+        rc = BD_FAILED;
+        rs = rs_; ri0 = ri0_; ri1 = ri1_; err_prev = 1.0; err_best = 1e300;
+        it = 0; it_best = 0;
+        sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
+        out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
+        out.iters = 0;
+        stage = S_NEWTON_S;
+    }
+
+    // INIT lanes: done, to be continued at the Newton iteration
+    PCS_DEV void handover() {
+        out.spec0 = rs; out.inc0 = ri0; out.inc1 = ri1;
+        rc = BD_HANDOVER;
+        stage = S_DONE;
     }
 
     // partial densities of this lane's next evaluation
@@ -130,7 +169,7 @@ struct BdLane {
             double p = e.p(), dp = r_x0 * e.dp0() + r_x1 * e.dp1();
             bool bad = false, done = false;
             double step = 0.0, rho_new = r_rho;
-            if (robust) {
+            if (MODE != BD_MODE_INIT && robust) {
                 bad = !is_finite_bits(p);
                 const bool above = (p > r_pspec) && (dp > 0.0);  // on the liquid branch above the root
                 if (!bad && r_phase == 0) {
@@ -224,7 +263,7 @@ struct BdLane {
                 return;
             }
             if (r_for == R_BUBBLE) {
-                if (robust && PCS_ROBUST_STAB_REJECT) {
+                if (MODE != BD_MODE_INIT && robust && PCS_ROBUST_STAB_REJECT) {
                     // the specified liquid must not lie deep inside a liquid-liquid spinodal: with M = d2(a + ideal)/drho_i drho_j,
                     // det M <= STAB_REJECT |M00 M11| gives the row up at once (a marginally unstable liquid, det M slightly
                     // negative, can still sit on a branch of the bubble curve that the iteration reaches: A/B on 50k rows with
@@ -235,7 +274,7 @@ struct BdLane {
                 rs = rho_new;
                 ri0 = (z0 * rs) * exp(g0c);  // ideal vapour at the liquid's fugacities
                 ri1 = (z1 * rs) * exp(g1c);
-                stage = S_NEWTON_S;
+                if (MODE == BD_MODE_INIT) handover(); else stage = S_NEWTON_S;
                 return;
             }
             // R_SS: this evaluation (one tiny step away from the root) serves as the sweep's evaluation
@@ -310,10 +349,12 @@ struct BdLane {
                 ri0 = x0 * rl;
                 ri1 = x1 * rl;
                 rs = p0;
-                stage = S_NEWTON_S;
+                if (MODE == BD_MODE_INIT) handover(); else stage = S_NEWTON_S;
             }
             return;
         }
+
+        if (MODE == BD_MODE_INIT) return;  // (no Newton stages in an INIT lane)
 
         if (stage == S_NEWTON_S) {
             sv = e;

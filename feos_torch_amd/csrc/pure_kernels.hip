@@ -403,7 +403,9 @@ __global__ __launch_bounds__(BLOCK, K4_WAVES) void k_pure_jacobian(const double*
                                                          const double* __restrict__ temp,
                                                          const double* __restrict__ pressure,
                                                          const double* __restrict__ rho_vl, int64_t n,
-                                                         double* __restrict__ jac) {
+                                                         double* __restrict__ jac, const double* __restrict__ gout,
+                                                         double* __restrict__ grad_params, double* __restrict__ grad_temp,
+                                                         double* __restrict__ grad_press, int polish) {
     __shared__ double lds[BLOCK * ROW_PAD];
     const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
     double par[8];
@@ -441,13 +443,38 @@ __global__ __launch_bounds__(BLOCK, K4_WAVES) void k_pure_jacobian(const double*
     const int64_t ii = live ? i : n - 1;
     const double T = temp[ii];
     const double p_pa = (WHICH == 1) ? pressure[ii] : 0.0;
-    const double rv = rho_vl[2 * ii], rl = rho_vl[2 * ii + 1];
+    double rv = rho_vl[2 * ii], rl = rho_vl[2 * ii + 1];
+    if (WHICH == 0 && polish) {
+        // densities from the pressure-only kernel (pcs_pure_vapor_pressure: ~1e-9 from the root on ordinary rows, 1e-5 close
+        // to the critical point where dp/drho -> 0): one fp64 Newton step of the coupled iteration (vle_step, quadratic) before
+        // the derivatives are taken; the pressure itself is not touched
+        PureCoef<double> cp;
+        pure_coef<double>(cp, par, T, false);
+        const Eval l = pure_eval(cp, rl), v = pure_eval(cp, rv);
+        const VleStep s = vle_step(l, v, rl, rv);
+        if (is_finite_bits(s.dl) && is_finite_bits(s.dv) && fabs(s.dl) < 0.1 * rl && fabs(s.dv) < 0.5 * rv) {
+            rl += s.dl;
+            rv += s.dv;
+        }
+    }
     double g[10];
     pure_jacobian<WHICH>(par, T, p_pa, rv, rl, g);
     if (!live) return;
     // a failed row carries zero densities -> NaNs; the caller masks by status
+    if (jac) {
 #pragma unroll
-    for (int k = 0; k < 10; k++) jac[10 * i + k] = g[k];
+        for (int k = 0; k < 10; k++) jac[10 * i + k] = g[k];
+    }
+    if (gout) {  // vector-Jacobian form (the backward pass of a property): upstream gradient folded in, no [n,10] round trip
+        const double w = gout[i];
+        if (grad_params) {
+            double2* dst = reinterpret_cast<double2*>(grad_params + 8 * i);
+#pragma unroll
+            for (int k = 0; k < 4; k++) dst[k] = make_double2(w * g[2 * k], w * g[2 * k + 1]);
+        }
+        if (grad_temp) grad_temp[i] = w * g[8];
+        if (grad_press) grad_press[i] = w * g[9];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -615,14 +642,41 @@ int pcs_pure_jacobian(int which, const double* params, const double* temp, const
     if (int e = check_n(n)) return e;
     if (n == 0) return 0;
     if (!params || !temp || !rho_vl || !jac) return fail_msg("pcs_pure_jacobian: null required pointer");
+    const int polish = (which & PCS_JAC_POLISH) ? 1 : 0;
+    which &= ~PCS_JAC_POLISH;
     if (which == 1 && !pressure) return fail_msg("pcs_pure_jacobian: pressure required for liquid_density");
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
     hipStream_t s = as_stream(stream);
     switch (which) {
-        case 0: hipLaunchKernelGGL(k_pure_jacobian<0>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac); break;
-        case 1: hipLaunchKernelGGL(k_pure_jacobian<1>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac); break;
-        case 2: hipLaunchKernelGGL(k_pure_jacobian<2>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac); break;
+        case 0: hipLaunchKernelGGL(k_pure_jacobian<0>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac, nullptr, nullptr, nullptr, nullptr, polish); break;
+        case 1: hipLaunchKernelGGL(k_pure_jacobian<1>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac, nullptr, nullptr, nullptr, nullptr, polish); break;
+        case 2: hipLaunchKernelGGL(k_pure_jacobian<2>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, jac, nullptr, nullptr, nullptr, nullptr, polish); break;
         default: return fail_msg("pcs_pure_jacobian: which must be 0, 1 or 2");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_jacobian launch", e);
+    return 0;
+}
+
+int pcs_pure_jacobian_vjp(int which, const double* params, const double* temp, const double* pressure, const double* rho_vl,
+                          const double* gout, int64_t n, double* grad_params, double* grad_temp, double* grad_pressure,
+                          void* stream) {
+    g_err[0] = 0;
+    if (int e = check_n(n)) return e;
+    if (n == 0) return 0;
+    if (!params || !temp || !rho_vl || !gout) return fail_msg("pcs_pure_jacobian_vjp: null required pointer");
+    const int polish = (which & PCS_JAC_POLISH) ? 1 : 0;
+    which &= ~PCS_JAC_POLISH;
+    if (which == 1 && !pressure) return fail_msg("pcs_pure_jacobian_vjp: pressure required for liquid_density");
+    if ((reinterpret_cast<uintptr_t>(grad_params) & 15) != 0) return fail_msg("pcs_pure_jacobian_vjp: grad_params must be 16-byte aligned");
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipStream_t s = as_stream(stream);
+    double* none = nullptr;
+    switch (which) {
+        case 0: hipLaunchKernelGGL(k_pure_jacobian<0>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, none, gout, grad_params, grad_temp, grad_pressure, polish); break;
+        case 1: hipLaunchKernelGGL(k_pure_jacobian<1>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, none, gout, grad_params, grad_temp, grad_pressure, polish); break;
+        case 2: hipLaunchKernelGGL(k_pure_jacobian<2>, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, rho_vl, n, none, gout, grad_params, grad_temp, grad_pressure, polish); break;
+        default: return fail_msg("pcs_pure_jacobian_vjp: which must be 0, 1 or 2");
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_pure_jacobian launch", e);

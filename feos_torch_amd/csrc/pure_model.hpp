@@ -167,6 +167,13 @@ PCS_DEV D2<double> horner_lin(const double* coef, const D2<double>& x) {
     }
     return D2<double>(p, d1 * x.d1, 2.0 * d2 * (x.d1 * x.d1));
 }
+// polynomial in the packing fraction zeta_3 given as Z: the two-variable Taylor types take horner_zeta (recurrence + one chain
+// rule); where zeta_3 is itself the first coordinate (Z = D2<double> with d1 = 1, d2 = 0) the recurrence IS the result
+template <int N, class P, class Z>
+PCS_DEV Z horner_z(const P* coef, const Z& x) { return horner_zeta<N>(coef, x); }
+template <int N>
+PCS_DEV D2<double> horner_z(const double* coef, const D2<double>& x) { return horner_lin<N>(coef, x); }
+
 // generic fall-back (gradient kernels): plain Horner in R arithmetic
 template <int N, class P, class R>
 PCS_DEV R horner_eta(const P* coef, const R& x) { return horner<N>(coef, x); }

@@ -94,7 +94,7 @@ def gather_rows(local, n_total, group=None, force=False):
 def _hip_vapor_pressure(params, temperature):
     from . import native
 
-    r = native.pure_vle(params, temperature, want_p=True)
+    r = native.pure_vapor_pressure(params, temperature)  # the kernel behind PcSaftPure.vapor_pressure
     return r["p_sat"], r["status"]
 
 

@@ -152,11 +152,16 @@ class Compaction:
         """Dense [n, ncol]: g[j] * src[j, col0:col0+ncol] in the row of the j-th kept entry, 0 in dropped rows (the scatter of
         a backward pass fused with its Jacobian product).  src [n_ok] or [n_ok, k] float64; 1-D src gives a 1-D result."""
         one_d = src.dim() == 1
-        src2 = src.contiguous().view(src.shape[0], -1)
-        stride = int(src2.shape[1])
+        stride = 1
+        for d in src.shape[1:]:
+            stride *= int(d)
+        src2 = src.contiguous().view(src.shape[0], stride)
         ncol = stride - col0 if ncol is None else ncol
         if src2.shape[0] != self.n_ok or (g is not None and g.shape[0] != self.n_ok):
             raise ValueError("src / g must have one row per kept row")
+        if self.n_ok == 0:  # nothing kept: all zeros (an empty tensor has no data pointer to hand to the kernel)
+            out = torch.zeros((self.n, ncol), dtype=_F64, device=self.device)
+            return out.view(self.n) if (one_d and ncol == 1) else out
         out = torch.empty((self.n, ncol), dtype=_F64, device=self.device)
         if self.n:
             L = _lib.lib()
@@ -234,8 +239,12 @@ def pure_derivatives(params, temperature, density):
 _WHICH = {"vapor_pressure": 0, "liquid_density": 1, "equilibrium_liquid_density": 2}
 
 
-def pure_jacobian(which, params, temperature, pressure, rho_vl):
-    """[n,10] Jacobian w.r.t. (8 parameters, T, p) at fixed densities."""
+JAC_POLISH = 0x100  # PCS_JAC_POLISH (include/pcsaft_hip.h)
+
+
+def pure_jacobian(which, params, temperature, pressure, rho_vl, polish=False):
+    """[n,10] Jacobian w.r.t. (8 parameters, T, p) at fixed densities.  polish: rho_vl are the pressure-only kernel's
+    densities (pure_vapor_pressure) and take one fp64 Newton step first."""
     device = rho_vl.device
     params = _prep(params, device, (8,))
     temperature = _prep(temperature, device)
@@ -246,10 +255,32 @@ def pure_jacobian(which, params, temperature, pressure, rho_vl):
     L = _lib.lib()
     with torch.cuda.device(device):
         jac = torch.empty((n, 10), dtype=_F64, device=device)
-        rc = L.pcs_pure_jacobian(_WHICH[which], _lib.ptr(params), _lib.ptr(temperature), _lib.ptr(pressure),
+        rc = L.pcs_pure_jacobian(_WHICH[which] | (JAC_POLISH if polish else 0), _lib.ptr(params), _lib.ptr(temperature), _lib.ptr(pressure),
                                  _lib.ptr(rho_vl), n, _lib.ptr(jac), _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_pure_jacobian")
     return jac
+
+
+def pure_jacobian_vjp(which, params, temperature, pressure, rho_vl, gout, need=(True, True, True), polish=False):
+    """Backward pass of a pure-component property on rows that all converged: (grad_params [n,8], grad_T [n], grad_p [n]) =
+    gout[:, None] * Jacobian, produced by the Jacobian kernel itself (pcs_pure_jacobian_vjp)."""
+    device = rho_vl.device
+    params = _prep(params, device, (8,))
+    temperature = _prep(temperature, device)
+    pressure = None if pressure is None else _prep(pressure, device)
+    rho_vl = _prep(rho_vl, device, (2,))
+    gout = _prep(gout, device)
+    n = temperature.shape[0]
+    _same_rows(n, parameters=params, pressure=pressure, rho_vl=rho_vl, gout=gout)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        gp = torch.empty((n, 8), dtype=_F64, device=device) if need[0] else None
+        gt = torch.empty(n, dtype=_F64, device=device) if need[1] else None
+        gpr = torch.empty(n, dtype=_F64, device=device) if (need[2] and pressure is not None) else None
+        rc = L.pcs_pure_jacobian_vjp(_WHICH[which] | (JAC_POLISH if polish else 0), _lib.ptr(params), _lib.ptr(temperature), _lib.ptr(pressure), _lib.ptr(rho_vl),
+                                     _lib.ptr(gout), n, _lib.ptr(gp), _lib.ptr(gt), _lib.ptr(gpr), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_pure_jacobian_vjp")
+    return gp, gt, gpr
 
 
 class PcSaft:
@@ -348,7 +379,7 @@ def mix_bubble_dew(params, kij, temperature, molefracs, pressure, dew, want_iter
         rho4 = torch.empty((n, 4), dtype=_F64, device=device)
         status = torch.empty(n, dtype=torch.uint8, device=device)
         iters = torch.empty(n, dtype=torch.int32, device=device) if want_iters else None
-        ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
+        ws = torch.empty(max(1, L.pcs_mix_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
         rc = L.pcs_mix_bubble_dew(int(bool(dew)), _lib.ptr(params), _lib.ptr(kij), _lib.ptr(temperature),
                                   _lib.ptr(molefracs), _lib.ptr(pressure), n, _lib.ptr(p), _lib.ptr(rho4),
                                   _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws), _lib.current_stream_ptr(device))

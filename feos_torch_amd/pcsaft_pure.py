@@ -57,9 +57,16 @@ class _PureProperty(torch.autograd.Function):
                 rho_vl = torch.stack([torch.zeros_like(root), root], dim=1)
             else:
                 rho_vl = comp.gather(rho_vl)
-            jac = native.pure_jacobian(which, comp.gather(par), comp.gather(T), None if P is None else comp.gather(P), rho_vl)
-            ctx.save_for_backward(jac)
+            if comp.all_ok:
+                # every row converged (the common case): the Jacobian kernel runs in backward, in vector-Jacobian form, and
+                # writes g * d value / d (parameters, T, p) straight into the gradient arrays
+                ctx.save_for_backward(par, T, rho_vl) if P is None else ctx.save_for_backward(par, T, rho_vl, P)
+            else:
+                jac = native.pure_jacobian(which, comp.gather(par), comp.gather(T), None if P is None else comp.gather(P), rho_vl,
+                                           polish=(which == "vapor_pressure"))
+                ctx.save_for_backward(jac)
             ctx.comp = comp
+            ctx.which = which
         ctx.needs = needs
         ctx.in_devices = (parameters.device, temperature.device, None if pressure is None else pressure.device)
         nans = nans.to(out_device)
@@ -68,10 +75,17 @@ class _PureProperty(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_value, _g_nans):
-        (jac,) = ctx.saved_tensors
         comp = ctx.comp
-        g = g_value.to(jac.device).contiguous()
+        g = g_value.to(comp.device).contiguous()
         gp = gt = gpr = None
+        if comp.all_ok:
+            par, T, rho_vl, *rest = ctx.saved_tensors
+            gp, gt, gpr = native.pure_jacobian_vjp(ctx.which, par, T, rest[0] if rest else None, rho_vl, g, ctx.needs,
+                                                   polish=(ctx.which == "vapor_pressure"))
+            dv = ctx.in_devices
+            return (None, None if gp is None else gp.to(dv[0]), None if gt is None else gt.to(dv[1]),
+                    None if gpr is None else gpr.to(dv[2]), None)
+        (jac,) = ctx.saved_tensors
         # dense gradient rows in one kernel each: g_j * jac[j, cols] scattered to the row's place, zeros for dropped rows
         if ctx.needs[0]:
             gp = comp.expand(jac, g, 0, 8).to(ctx.in_devices[0])

@@ -102,14 +102,25 @@ int pcs_pure_derivatives(const double* params, const double* temp, const double*
  * Jacobian of a pure-component property w.r.t. its inputs with the phase densities held
  * fixed — what torch reverse mode through the reference's Python tail yields
  * (feos_torch/pcsaft_pure.py:196-199 / :212-215 / :228-233).
- *   which    0 = vapor_pressure, 1 = liquid_density, 2 = equilibrium_liquid_density
+ *   which    0 = vapor_pressure, 1 = liquid_density, 2 = equilibrium_liquid_density; 0 | PCS_JAC_POLISH: rho_vl comes
+ *            from pcs_pure_vapor_pressure (~1e-9 from the root) and takes one fp64 Newton step before the derivatives
  *   pressure [n]    in  Pa (which = 1 only, else NULL)
  *   rho_vl   [n,2]  in  A^-3 (rho_V, rho_L) from pcs_pure_vle; for which = 1 column 1 holds
  *                       rho_root from pcs_pure_liquid_density, column 0 is ignored
  *   jac      [n,10] out d value / d (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab, na, nb, T, p)
  */
+#define PCS_JAC_POLISH 0x100
 int pcs_pure_jacobian(int which, const double* params, const double* temp, const double* pressure,
                       const double* rho_vl, int64_t n, double* jac, void* stream);
+
+/*
+ * The same Jacobian in vector-Jacobian form -- the backward pass of a property call: grad_x[i] = gout[i] * d value_i / d x_i
+ * written straight into the dense gradient arrays (no [n,10] round trip through memory).
+ *   gout [n] in; grad_params [n,8] (16-byte aligned), grad_temp [n], grad_pressure [n] out, each optional.
+ */
+int pcs_pure_jacobian_vjp(int which, const double* params, const double* temp, const double* pressure, const double* rho_vl,
+                          const double* gout, int64_t n, double* grad_params, double* grad_temp, double* grad_pressure,
+                          void* stream);
 
 /*
  * Binary-mixture bubble point (dew = 0: z = liquid mole fraction of component 1) or dew point
@@ -125,10 +136,12 @@ int pcs_pure_jacobian(int which, const double* params, const double* temp, const
  *   rho4    [n,4]   out   A^-3 (rhoV_1, rhoV_2, rhoL_1, rhoL_2), src/pcsaft.rs:225-228 (optional)
  *   status  [n]     out   uint8, 1 = failed
  *   iters   [n]     out   int32 Newton iterations (optional)
- *   workspace       device scratch of pcs_workspace_bytes(n) for the work-queue schedule (rows ordered by
- *                   class on the device, persistent waves, a lane that finishes a row takes the next one);
+ *   workspace       device scratch of pcs_mix_workspace_bytes(n) for the work-queue schedule (rows ordered by
+ *                   class on the device, a pre-pass with the pure-component fugacities of Raoult's law, persistent
+ *                   waves, a lane that finishes a row takes the next one);
  *                   NULL = one row per lane in a single pass (same results, several times slower)
  */
+int64_t pcs_mix_workspace_bytes(int64_t n);
 int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const double* temp, const double* z,
                        const double* p_init, int64_t n, double* p_out, double* rho4, uint8_t* status, int32_t* iters,
                        void* workspace, void* stream);

@@ -75,7 +75,7 @@ def test_two_schedules_agree_including_the_second_pass():
             p = torch.empty(n, dtype=torch.float64, device=dev)
             rho4 = torch.empty((n, 4), dtype=torch.float64, device=dev)
             st = torch.empty(n, dtype=torch.uint8, device=dev)
-            ws = torch.empty(L.pcs_workspace_bytes(n) // 4, dtype=torch.int32, device=dev) if use_ws else None
+            ws = torch.empty(L.pcs_mix_workspace_bytes(n) // 4, dtype=torch.int32, device=dev) if use_ws else None
             rc = L.pcs_mix_bubble_dew(dew, *[_lib.ptr(a) for a in args], n, _lib.ptr(p), _lib.ptr(rho4), _lib.ptr(st), None,
                                       _lib.ptr(ws), _lib.current_stream_ptr(dev))
             assert rc == 0

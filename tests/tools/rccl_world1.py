@@ -28,7 +28,7 @@ Pd, Td = torch.from_numpy(P).to(device), torch.from_numpy(T).to(device)
 
 # 1. the product schedule with the collective forced: shard solve -> all_gather_into_tensor of p (f64) and status (u8)
 p, st = pdist.sharded_vapor_pressure(Pd, Td, force_collective=True)
-ref = native.pure_vle(Pd, Td, want_p=True, want_rho_vl=False)
+ref = native.pure_vapor_pressure(Pd, Td)
 same_p = bool(torch.equal(p, ref["p_sat"]))
 same_st = bool(torch.equal(st, ref["status"]))
 
