@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_mix_class_scatter(const double* __restr
 // instructions instead of 1,600-3,500), one (row, component) per lane, four waves per SIMD.  Results agree with the
 // state machine's to rounding; a lane the plain form would give up on writes NaN and the row takes the state machine's own
 // route (including its robust second attempt), so no decision of the solver changes.
-// fug[2 k + c] = rho_L exp(mu_res) of component c of the row at queue position k at p = 0, or NaN.
+// fug[4 k + c] = rho_L exp(mu_res) of component c of the row at queue position k at p = 0, or NaN; fug[4 k + 2 + c] = rho_L.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mix_pure_fugacity(const double* __restrict__ params, const double* __restrict__ temp,
                                                            int64_t n, const int32_t* __restrict__ perm,
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_mix_pure_fugacity(const double* __restr
     PureCoef<double> c;
     pure_coef<double>(c, par, T, false);
     const double pk = c.ceta;
-    double rho = 0.5 / pk, err_prev = 1.0, f = __longlong_as_double(0x7ff8000000000000LL);
+    double rho = 0.5 / pk, err_prev = 1.0, f = __longlong_as_double(0x7ff8000000000000LL), rho_root = 0.0;
     bool dense = false, active = live && usable;
     int it = 0;
     for (int guard = 0; guard < LIQ_ROOT_MAX_IT + 2; guard++) {
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void k_mix_pure_fugacity(const double* __restr
                     active = false;  // NaN: the state machine decides (robust second attempt)
                 } else if (done) {
                     f = rho_new * exp(a.d1 - a.d2 * step);  // chemical potential carried to the root to first order
+                    rho_root = rho_new;
                     active = false;
                 } else {
                     rho = rho_new;
@@ -278,7 +279,10 @@ __global__ __launch_bounds__(256) void k_mix_pure_fugacity(const double* __restr
         }
         if (__ballot(active) == 0ull) break;
     }
-    if (live) fug[2 * pos + comp] = f;
+    if (live) {
+        fug[4 * pos + comp] = f;
+        fug[4 * pos + 2 + comp] = rho_root;
+    }
 }
 
 // One wave's slice of a queue [0, total): hands `rank`-th idle lane the queue position next + rank.  Wave-uniform state.
@@ -357,13 +361,9 @@ __global__ __launch_bounds__(64, 1) void k_mix_init_queue(const double* __restri
             if (L.done() && ((need >> lane) & 1ull) && rank < avail) {
                 pos = q.next + rank;
                 const RowScalars r = take_row(params, kij, temp, z, p_init, perm[pos], m);
-                double f0 = -1.0, f1 = -1.0;
-                if (DEW && fug) {
-                    const double2 ff = reinterpret_cast<const double2*>(fug)[pos];  // k_mix_pure_fugacity; NaN = not pre-solved
-                    f0 = ff.x;
-                    f1 = ff.y;
-                }
-                L.start(m, r.z, r.p_red, SS_MAX_IT, NEWTON_MAX_IT, false, f0, f1);
+                double4 ff = make_double4(-1.0, -1.0, 0.0, 0.0);
+                if (DEW && fug) ff = reinterpret_cast<const double4*>(fug)[pos];  // k_mix_pure_fugacity; NaN = not pre-solved
+                L.start(m, r.z, r.p_red, SS_MAX_IT, NEWTON_MAX_IT, false, ff.x, ff.y, ff.z, ff.w);
                 evals = 0;
             }
             const int wanted = __popcll(need);
@@ -597,10 +597,11 @@ int queue_waves() {
 extern "C" {
 
 // workspace of pcs_mix_bubble_dew: row order perm[n] + control block (as pcs_workspace_bytes), then -- 16-byte aligned --
-// the pre-pass fugacities (2 doubles per row), the init records (4 doubles per row) and the robust list (1 int per row)
+// the pre-pass fugacities and densities (4 doubles per row), the init records (4 doubles per row) and the robust list (1 int
+// per row)
 int64_t pcs_mix_workspace_bytes(int64_t n) {
     const int64_t m = n > 0 ? n : 0;
-    return mix_ws_offset(n) + (int64_t)sizeof(double) * 6 * m + (int64_t)sizeof(int32_t) * m;
+    return mix_ws_offset(n) + (int64_t)sizeof(double) * 8 * m + (int64_t)sizeof(int32_t) * m;
 }
 
 int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const double* temp, const double* z,
@@ -616,8 +617,8 @@ int pcs_mix_bubble_dew(int dew, const double* params, const double* kij, const d
         int32_t* perm = static_cast<int32_t*>(workspace);
         int32_t* ctrl = perm + n;
         double* fug = reinterpret_cast<double*>(static_cast<char*>(workspace) + mix_ws_offset(n));
-        double4* init = reinterpret_cast<double4*>(fug + 2 * n);
-        int32_t* robust_list = reinterpret_cast<int32_t*>(fug + 6 * n);
+        double4* init = reinterpret_cast<double4*>(fug + 4 * n);
+        int32_t* robust_list = reinterpret_cast<int32_t*>(fug + 8 * n);
         if (int ez = zero_ints(ctrl, QCTRL_INTS, s)) return ez;
         const unsigned g256 = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_mix_class_count, dim3(g256), dim3(256), 0, s, params, n, ctrl);

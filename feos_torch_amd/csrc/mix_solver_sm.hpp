@@ -68,7 +68,7 @@ struct BdLane {
     int r_phase, r_k;     // robust: 0 = looking for hi among the candidates, 1 = walking down for lo, 2 = safeguarded Newton
     double r_lo, r_hi;    // robust: bracket of the root
     // dew initialisation
-    double f0, x0, x1, p0, rl, xi_prev, res_prev, xi_lo, xi_hi;
+    double f0, rl0, x0, x1, p0, rl, xi_prev, res_prev, xi_lo, xi_hi;  // rl0: zero-pressure liquid density of pure component 0
     int ss;
     bool resolved;
     // Newton
@@ -103,13 +103,13 @@ struct BdLane {
 
     template <class Model>
     PCS_DEV void start(const Model& m, double z0_, double p_init_, int ss_max_ = SS_MAX_IT, int newton_max_ = NEWTON_MAX_IT,
-                       bool robust_ = false, double fug0 = -1.0, double fug1 = -1.0) {
+                       bool robust_ = false, double fug0 = -1.0, double fug1 = -1.0, double rho0_ = 0.0, double rho1_ = 0.0) {
         robust = robust_;
         root_failed = false;
         z0 = z0_; z1 = 1.0 - z0_; p_init = p_init_;
         ss_max = ss_max_; newton_max = newton_max_;
         rc = BD_FAILED;
-        f0 = 0.0; x0 = z0; x1 = z1; p0 = p_init; rl = 0.0; xi_prev = 0.0; res_prev = 0.0; xi_lo = -1e300; xi_hi = 1e300;
+        f0 = 0.0; rl0 = 0.0; x0 = z0; x1 = z1; p0 = p_init; rl = 0.0; xi_prev = 0.0; res_prev = 0.0; xi_lo = -1e300; xi_hi = 1e300;
         ss = 0;
         resolved = false;
         rs = 0.0; ri0 = 0.0; ri1 = 0.0; err_prev = 1.0; err_best = 1e300;
@@ -121,12 +121,31 @@ struct BdLane {
             // pure-liquid fugacities from the pre-pass (k_mix_pure_fugacity: the same two roots on the pure-component
             // evaluation): straight to Raoult's law, as after R_PURE1 below
             f0 = fug0;
-            p0 = 1.0 / (z0 / fug0 + z1 / fug1);
-            x0 = z0 * p0 / fug0;
-            x1 = z1 * p0 / fug1;
-            start_root(m, R_SS, x0, x1, 0.0, true, p0);
+            rl0 = rho0_;
+            raoult(m, fug1, rho1_);
         } else if (DEW) start_root(m, R_PURE0, 1.0, 0.0, 0.0, false, 0.0);
         else start_root(m, R_BUBBLE, z0, z1, p_init, true, 0.0);
+    }
+
+    // Raoult's law from the pure-liquid fugacities (f0, f1) and the start of the successive substitution.  The liquid at the
+    // Raoult composition starts at the ideal-mixing (Amagat) density of the two pure liquids, 1/rho = x_0/rho_0 + x_1/rho_1,
+    // and goes straight into the first sweep: its evaluation carries the density to the zero-pressure root by the Newton step
+    // it provides (as every later sweep does), or, if that step is not small, asks for the root from there -- instead of a
+    // cold root solve from eta = 0.5 before the first sweep (2-3 evaluations per dew row; round 3).  Plain form only: the
+    // robust second attempt keeps its bracketed root.
+    template <class Model>
+    PCS_DEV void raoult(const Model& m, double f1, double rl1) {
+        p0 = 1.0 / (z0 / f0 + z1 / f1);
+        x0 = z0 * p0 / f0;
+        x1 = z1 * p0 / f1;
+        const double amagat = 1.0 / (x0 / rl0 + x1 / rl1);
+        if (!robust && rl0 > 0.0 && rl1 > 0.0 && is_finite_bits(amagat) && amagat > 0.0) {
+            rl = amagat;
+            resolved = false;
+            stage = S_SS;
+        } else {
+            start_root(m, R_SS, x0, x1, 0.0, true, p0);
+        }
     }
 
     // continue a row an INIT lane has initialised: the Newton iteration from (rho_spec, rho_inc_1, rho_inc_2);
@@ -251,15 +270,12 @@ struct BdLane {
             const double g1c = e.g1 - (r_x0 * e.h01 + r_x1 * e.h11) * step;
             if (r_for == R_PURE0) {
                 f0 = rho_new * exp(g0c);
+                rl0 = rho_new;
                 PCS_SM_START_ROOT(R_PURE1, 0.0, 1.0, 0.0, false, 0.0);
                 return;
             }
             if (r_for == R_PURE1) {
-                const double f1 = rho_new * exp(g1c);
-                p0 = 1.0 / (z0 / f0 + z1 / f1);  // Raoult
-                x0 = z0 * p0 / f0;
-                x1 = z1 * p0 / f1;
-                PCS_SM_START_ROOT(R_SS, x0, x1, 0.0, true, p0);
+                raoult(m, rho_new * exp(g1c), rho_new);
                 return;
             }
             if (r_for == R_BUBBLE) {

@@ -225,7 +225,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         for (int i = 0; i < 2; i++) ri[i] = r[i] * exp(e.g[i]);
     } else {
         // Raoult: zero-pressure pure-liquid fugacities f_i, p = 1/sum(y_i/f_i), x_i = y_i p/f_i
-        F f[2];
+        F f[2], rho_pure[2] = {F(0), F(0)};
         bool ok = true;
         for (int i = 0; i < 2; i++) {
             F xi[2] = {i == 0 ? F(1) : F(0), i == 1 ? F(1) : F(0)};
@@ -239,6 +239,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             F r[2] = {xi[0] * rho0, xi[1] * rho0};
             PhaseEval<F> e = eval_phase<F>(model, T, r);
             f[i] = rho0 * exp(e.g[i]);
+            rho_pure[i] = rho0;
         }
         F x[2], p0;
         if (ok) {
@@ -255,6 +256,13 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         //   x_i <- (y_i x_i / f_i) / sum_j (y_j x_j / f_j),   p = 1 / sum_j (y_j x_j / f_j)
         F rl = 0;
         bool have = false;
+        if (ok && !robust) {
+            // plain form: the liquid at the Raoult composition starts at the ideal-mixing (Amagat) density of the two pure
+            // liquids and goes straight into the first sweep (as csrc/mix_solver_sm.hpp::raoult): the sweep's own Newton step
+            // carries it to the zero-pressure root, or asks for the root from there
+            F am = F(1) / (x[0] / rho_pure[0] + x[1] / rho_pure[1]);
+            if (am > 0 && am == am && am * F(2) != am) { rl = am; have = true; }
+        }
         static const bool ss_secant = getenv("ORC_SS_PLAIN") == nullptr;
         static const bool ss_track = getenv("ORC_SS_NOTRACK") == nullptr;
         F xi_prev = 0, res_prev = 0;

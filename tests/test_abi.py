@@ -35,7 +35,7 @@ def test_abi_version_and_error_string(hip_lib):
     assert hip_lib.pcs_abi_version() >= 100
     assert hip_lib.pcs_last_error() == b""
     assert hip_lib.pcs_workspace_bytes(1000) == 4 * (1000 + 64)  # row order / retry list + control block
-    assert hip_lib.pcs_mix_workspace_bytes(1000) == 4 * (1000 + 64) + (16 + 32 + 4) * 1000  # + fugacities, init records, robust list
+    assert hip_lib.pcs_mix_workspace_bytes(1000) == 4 * (1000 + 64) + (32 + 32 + 4) * 1000  # + fugacities and densities, init records, robust list
 
 
 def test_argument_validation_without_gpu(hip_lib):
