@@ -41,15 +41,12 @@ template <int MODE> struct GsChunk { static constexpr int value = MODE == 0 ? 2 
 
 enum : int { Q_M, Q_Z1, Q_Z2, Q_Z3, Q_S3, Q_EK, Q_MU, Q_SA, Q_EA, Q_KA, Q_EAB, Q_NA, Q_NB, Q_COUNT };
 
-// Accumulation into the workgroup's [S,8] gradient table in LDS: ds_add_f64 per contributing lane (PCS_GC_WAVE_ACC = 0).
-// PCS_GC_WAVE_ACC = 1 (experiment, off): the workgroup is ONE wave and with class-ordered rows many of its lanes add to the
+// Accumulation into the workgroup's [S,8] gradient table in LDS: ds_add_f64 per contributing lane (0 = 0).
+// 0 = 1 (experiment, off): the workgroup is ONE wave and with class-ordered rows many of its lanes add to the
 // same table entry at the same time; there the lanes that target the same entry are summed with a DPP butterfly and ONE
 // lane does a plain read-modify-write, once per distinct entry in the wave.  Measured on 1e6 rows: 6.55 ms against 4.71 ms
 // with the atomics -- the waits of this kernel (PMC: 71 % of the wave cycles) are not the LDS atomics.  Either way every
 // lane of the wave reaches the call (on = this lane contributes).
-#ifndef PCS_GC_WAVE_ACC
-#define PCS_GC_WAVE_ACC 0
-#endif
 __device__ __forceinline__ double wave_sum(double x) {
 #define PCS_DPP_STEP(ctrl, rmask)                                                                \
     {                                                                                            \
@@ -67,20 +64,7 @@ __device__ __forceinline__ double wave_sum(double x) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
 __device__ __forceinline__ void lds_add(double* p, double v, bool on) {
-#if PCS_GC_WAVE_ACC
-    const unsigned a32 = (unsigned)(uintptr_t)p;
-    unsigned long long todo = __ballot(on);
-    while (todo != 0ull) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const unsigned la = (unsigned)__builtin_amdgcn_readlane((int)a32, leader);
-        const bool mine = on && a32 == la;
-        const double tot = wave_sum(mine ? v : 0.0);
-        if ((int)threadIdx.x == leader) *p += tot;
-        todo &= ~__ballot(mine);
-    }
-#else
     if (on) unsafeAtomicAdd(p, v);
-#endif
 }
 
 // d and its derivatives w.r.t. sigma and epsilon_k of the segment (:118-120)
@@ -127,9 +111,6 @@ __device__ __attribute__((noinline)) void gc_finish_tangent(GcCoef<G>& c, const 
     gc_finish<G, G>(c, g, phi0, phi1, G(rT));
 }
 
-#ifndef PCS_GC_ADJOINT
-#define PCS_GC_ADJOINT 1  // MODE 0: coefficient adjoints (mix_adjoint.hpp) instead of 13 dual-number passes through both phases
-#endif
 
 // Coefficient adjoints of the gc Helmholtz energy along (q, b), as mix_a_adjoint (mix_adjoint.hpp): shared packing / hard
 // sphere / dispersion / dipole part, the bond-based chain term (only its packing-sum dependence here: the bond diameters
@@ -463,7 +444,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
             }
         };
         // ---- (1) molecule-level sums -------------------------------------------------------------------------------
-        if constexpr (MODE == 0 && PCS_GC_ADJOINT) {
+        if constexpr (MODE == 0 && 1) {
             // coefficient adjoints of both phases (closed form), then their chain to the 26 sums
             double* adj = reinterpret_cast<double*>(gbonds) + threadIdx.x;
 #pragma unroll

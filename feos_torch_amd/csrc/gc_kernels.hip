@@ -11,35 +11,18 @@
 #include "gc_kernel_common.hpp"
 #include "mix_solver.hpp"
 #include "mix_solver_sm.hpp"
-#ifndef PCS_MIX_SM
-#define PCS_MIX_SM 1  // 1: state-machine form of the solver (mix_solver_sm.hpp), 0: sequential form
-#endif
-#if PCS_MIX_SM
-#define PCS_BD_SOLVE bubble_dew_solve_sm
-#else
-#define PCS_BD_SOLVE bubble_dew_solve
-#endif
 
 using namespace pcs;
 using namespace pcs_abi;
 
 namespace {
 
-#ifndef PCS_GBLOCK
-#define PCS_GBLOCK 128
-#endif
+constexpr int PCS_GBLOCK = 128;
 constexpr int GBLOCK = PCS_GBLOCK;
 constexpr int GJBLOCK = 64;
 
-#ifndef PCS_GC_BUCKET
-#define PCS_GC_BUCKET 1
-#endif
-#ifndef PCS_GC_FAST_SS
-#define PCS_GC_FAST_SS 6  // A/B on the synthetic dew batch (scripts/dev/ab_gc.py): 12/12: 9.0 ms, 6/8: 7.9, 4/8: 8.4, 7/7: 8.6
-#endif
-#ifndef PCS_GC_FAST_NEWTON
-#define PCS_GC_FAST_NEWTON 8
-#endif
+constexpr int PCS_GC_FAST_SS = 6;  // A/B on the synthetic dew batch (scripts/dev/ab_gc.py): 12/12: 9.0 ms, 6/8: 7.9, 4/8: 8.4, 7/7: 8.6
+constexpr int PCS_GC_FAST_NEWTON = 8;
 constexpr int GC_FAST_SS = PCS_GC_FAST_SS, GC_FAST_NEWTON = PCS_GC_FAST_NEWTON;  // fast-pass caps (mix_solver.hpp)
 constexpr int GC_RETRY_BLOCKS = 1024;
 
@@ -115,7 +98,6 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
         const int64_t o = first < n ? (int64_t)order[first] : n;
         first = (o >= 0 && o < n) ? o : n;  // a foreign order array must not fault
     }
-#if PCS_GC_BUCKET
     if (!RETRY && !order) {
         // rows of the workgroup bucketed by class (LDS counting sort): lane t takes the row at sorted position t, so a
         // wave mostly runs one set of branches of the evaluation
@@ -142,7 +124,6 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
         __syncthreads();
         first = (int64_t)blockIdx.x * GBLOCK + perm[t];
     }
-#endif
     const int64_t total = RETRY ? min((int64_t)max(retry[0], 0), n) : n;  // count and entries bounded by n: a foreign list must not fault
     const int64_t stride = RETRY ? (int64_t)gridDim.x * GBLOCK : total;  // fast pass: one row per lane
     for (int64_t k = first; k < total; k += stride) {
@@ -153,15 +134,11 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
         MixResult r;
         const double p_red = p_init[i] / (T * P_UNIT);
         const bool fast = !RETRY && retry;
-#if PCS_MIX_SM
         bool root_failed = false;
         int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT, false, &root_failed);
         // a row that fails at a liquid root with the full caps gets the robust second attempt (bracketed liquid roots,
         // mix_solver_sm.hpp): in the second pass, or in place when there is no work list
         if (!fast && rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
-#else
-        int rc = PCS_BD_SOLVE<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT);
-#endif
         if (fast && rc != BD_OK) {  // cap hit or failed: the second pass decides
             status[i] = 1;  // provisional
             const int slot = atomicAdd(&retry[0], 1);

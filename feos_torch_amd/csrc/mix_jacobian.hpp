@@ -19,13 +19,10 @@
 namespace pcs {
 
 constexpr int MIX_DIRS = 19;  // 16 parameters (component 0 then 1), k_ij, eps_AiBj, T
-#ifndef PCS_MIX_CHUNK
 // directions per pass; A/B on 1e6 rows: 1: 13.3 ms, 2: 9.8 ms, 3: 10.4 ms.  The kernel's stack frame (coefficient struct
 // with tangents + spills) must stay small: at 2.5-4 KB per lane the runtime throttles the resident waves (measured:
 // 21 ms, and bimodal with the launch history); with the coefficient set-up out of line it is 2.2 KB for 2 directions
-#define PCS_MIX_CHUNK 2
-#endif
-constexpr int MIX_CHUNK = PCS_MIX_CHUNK;
+constexpr int MIX_CHUNK = 2;
 // Direction handled by slot j of a pass (-1: none).  With two directions per pass they are paired so that the
 // structurally-zero ones share passes (both dipole moments; the association parameters of one component; eps_AiBj alone):
 // a non-polar non-associating row runs 4 passes instead of 6, an associating one skips the eps_AiBj pass unless it is used.
@@ -88,12 +85,7 @@ __device__ __attribute__((noinline)) void mix_coef_tangent(MixCoef<G>& c, const 
 // spec_is_vapor: the pressure functional is always taken on the VAPOUR phase (p^S for dew, p^I for
 // bubble): the liquid-phase pressure is a difference of O(0.1) terms, so its explicit parameter
 // derivative would have to cancel against w . dF/dtheta to the size of p itself.
-#ifndef PCS_MIX_ADJOINT
-#define PCS_MIX_ADJOINT 1  // coefficient adjoints (mix_adjoint.hpp) + forward tangents of the coefficient set only; 0: tangents through everything
-#endif
-#ifndef PCS_MIX_ADJ_CHUNK
-#define PCS_MIX_ADJ_CHUNK 3  // A/B 1e6 rows: 2: 2.6 ms, 3: 2.5, 4: 2.5, 5: 3.0, 7: 3.8, 10: 5.1 (spills of the pass function)
-#endif
+constexpr int PCS_MIX_ADJ_CHUNK = 3;  // A/B 1e6 rows: 2: 2.6 ms, 3: 2.5, 4: 2.5, 5: 3.0, 7: 3.8, 10: 5.1 (spills of the pass function)
 constexpr int MIX_ADJ_CHUNK = PCS_MIX_ADJ_CHUNK;  // parameter directions per pass over mix_coef in the adjoint form
 
 // one pass of the adjoint form: e[j] = d/dtheta_{d0+j} sum_k adj[k] c_k(theta), the coefficient set with MIX_ADJ_CHUNK tangents
@@ -126,9 +118,6 @@ __device__ __attribute__((noinline)) void mix_adjoint_pass(const double* __restr
 // on 9; the association strengths on 14 -- so each is differentiated forward with just those seeded (DN<4>, DN<8>, DN<9>,
 // DN<14> over a small function) instead of 19 directions through the whole coefficient set (7 DN<3> passes: 19 k
 // instructions per row; this form: 1.5 k for a non-polar non-associating row, ~6 k with both).
-#ifndef PCS_MIX_COEF_BLOCKS
-#define PCS_MIX_COEF_BLOCKS 1
-#endif
 template <class G> struct MixCompOut { G m[2], mm1[2], d[2], zk[4][2]; };
 template <class G> struct MixDispOut { G A[3], B[3]; };
 template <class G> struct MixAssocIO { int acls; G na[2], nb[2], d[2], dij[3], S[3]; };
@@ -278,7 +267,6 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
         alpha[0] = w[2];   beta0[0] = -w[2] * s0 - w[0]; beta1[0] = -w[2] * s1 - w[1];
         alpha[1] = -u;     beta0[1] = u * i0 + w[0];     beta1[1] = u * i1 + w[1];
     }
-#if PCS_MIX_ADJOINT
     {
         // dp/dtheta = T kB/A^3 sum_k abar_k dc_k/dtheta (+ p/T for theta = T) with the coefficient adjoints
         // abar = sum over the phases of d/dc [alpha a + beta . grad a], closed form (mix_adjoint.hpp)
@@ -290,7 +278,6 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
             const double al = ph == 0 ? alpha[0] : alpha[1], b0 = ph == 0 ? beta0[0] : beta0[1], b1 = ph == 0 ? beta1[0] : beta1[1];
             mix_a_adjoint(m.c, q0, q1, b0, b1, al, adj, adj_stride);
         }
-#if PCS_MIX_COEF_BLOCKS
         double e[MIX_DIRS];
         mix_coef_gradient(par, k0, k1, T, adj, adj_stride, e);
 #pragma unroll
@@ -300,77 +287,7 @@ PCS_DEV void mix_jacobian(const double par[16], double k0, double k1, double T, 
             if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
             g[d] = val;
         }
-#else
-#pragma unroll 1
-        for (int d0 = 0; d0 < MIX_DIRS; d0 += MIX_ADJ_CHUNK) {
-            double e[MIX_ADJ_CHUNK];
-            mix_adjoint_pass(par, k0, k1, T, d0, adj, adj_stride, e);
-#pragma unroll
-            for (int j = 0; j < MIX_ADJ_CHUNK; j++) {
-                const int d = d0 + j;
-                if (d < MIX_DIRS) {
-                    double val = e[j] * T * P_UNIT;
-                    if (d == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
-                    if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
-                    g[d] = val;
-                }
-            }
-        }
-#endif
     }
-#else
-    constexpr int NPASS = (MIX_DIRS + MIX_CHUNK - 1) / MIX_CHUNK;
-    // directions whose derivative is structurally zero: a dipole moment of 0 (the term is quadratic in it), every
-    // association parameter when no component associates (the term is absent), eps_AiBj unless it is in use
-    const bool no_assoc = m.c.acls == ASSOC_NONE;
-    const bool eab_used = m.c.acls == ASSOC_CROSS && k1 != 0.0;
-#pragma unroll 1
-    for (int pass = 0; pass < NPASS; pass++) {
-        {
-            bool zero = true;  // every direction of this pass is structurally zero for this row
-#pragma unroll
-            for (int j = 0; j < MIX_CHUNK; j++) {
-                const int d = mix_direction(pass, j), kk = d & 7;
-                bool zj = true;
-                if (d < 0) zj = true;
-                else if (d < 16) zj = (kk == 3 && par[d] == 0.0) || (kk >= 4 && no_assoc);
-                else if (d == 17) zj = !eab_used;
-                else if (d < MIX_DIRS) zj = false;
-                zero = zero && zj;
-            }
-            if (__ballot(!zero) == 0ull) {  // the whole wave skips the pass
-#pragma unroll
-                for (int j = 0; j < MIX_CHUNK; j++)
-                    if (mix_direction(pass, j) >= 0) g[mix_direction(pass, j)] = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
-                continue;
-            }
-        }
-        MixCoef<G> c;
-        mix_coef_tangent<G>(c, par, k0, k1, T, pass);
-        // both phases through ONE evaluation site (loop not unrolled, evaluation not inlined): the dual-number
-        // evaluation is large, two inlined copies per pass cost ~5,000 spilled VGPRs
-        double acc[MIX_CHUNK];
-#pragma unroll
-        for (int j = 0; j < MIX_CHUNK; j++) acc[j] = 0.0;
-#pragma unroll 1
-        for (int ph = 0; ph < 2; ph++) {
-            const double q0 = ph == 0 ? s0 : i0, q1 = ph == 0 ? s1 : i1;
-            const double al = ph == 0 ? alpha[0] : alpha[1], b0 = ph == 0 ? beta0[0] : beta0[1], b1 = ph == 0 ? beta1[0] : beta1[1];
-            R a = mix_a_tangent<G, R>(c, R(G(q0), G(b0)), R(G(q1), G(b1)));
-#pragma unroll
-            for (int j = 0; j < MIX_CHUNK; j++) acc[j] += al * a.v.e[j] + a.d1.e[j];
-        }
-#pragma unroll
-        for (int j = 0; j < MIX_CHUNK; j++) {
-            const double dp = acc[j];
-            double val = dp * T * P_UNIT;
-            const int d = mix_direction(pass, j);
-            if (d == 18) val += p_red * P_UNIT;  // p [Pa] = p_red T kB/A^3
-            if (!ok) val = __longlong_as_double(0x7ff8000000000000LL);
-            if (d >= 0) g[d] = val;
-        }
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -45,9 +45,7 @@ __device__ __forceinline__ void load_mix_row(const double* __restrict__ params, 
 
 // lanes that must be idle before a queue wave refills: the refill code (row load, coefficient set-up) runs for the whole
 // wave (A/B dew 1e6 rows, round 1, one kernel: 1: 7.9 ms, 4: 7.7, 8: 7.5, 16: 7.8; round 3, two kernels: 8: 4.93, 12: 4.84, 16: 4.83, 24: 4.89)
-#ifndef PCS_REFILL_MIN
-#define PCS_REFILL_MIN 16
-#endif
+constexpr int PCS_REFILL_MIN = 16;
 constexpr int REFILL_MIN = PCS_REFILL_MIN;
 
 constexpr int MIX_BINS = 8;
@@ -512,9 +510,7 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* 
     // bucketed inside the workgroup as in k_mix_bubble_dew
     __shared__ int perm[MBLOCK];
     __shared__ int bins[MIX_BINS + 1];
-#if PCS_MIX_ADJOINT
     __shared__ double adj_lds[ADJ_SLOTS * MBLOCK];  // coefficient adjoints of this lane's row: adj_lds[k * MBLOCK + t]
-#endif
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * MBLOCK;
     int64_t i;
@@ -548,11 +544,7 @@ __global__ __launch_bounds__(MBLOCK) void k_mix_jacobian(int dew, const double* 
     load_mix_row(params, kij, i, par, k0, k1);
     double4 r = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
     double* g = jac + MIX_DIRS * i;
-#if PCS_MIX_ADJOINT
     double* adj = adj_lds + t;
-#else
-    double* adj = nullptr;
-#endif
     if (dew) mix_jacobian(par, k0, k1, temp[i], r.x, r.y, r.z, r.w, true, g, adj, MBLOCK);
     else mix_jacobian(par, k0, k1, temp[i], r.z, r.w, r.x, r.y, false, g, adj, MBLOCK);
 }

@@ -1,7 +1,7 @@
-// bubble_dew_solve as a per-lane state machine around ONE evaluation site (device only).
+// The bubble / dew solve as a per-lane state machine around ONE evaluation site (device only).
 //
-// Same algorithm, constants and decisions as bubble_dew_solve() in mix_solver.hpp (which documents
-// them and which the CPU oracle restates); what changes is the control flow.  The sequential form
+// The algorithm and its constants are documented in mix_solver.hpp; the CPU oracle (oracle/mix_solver.hpp) restates it
+// sequentially, decision by decision.  A sequential form
 // nests loops (pure-liquid roots, successive substitution with occasional root re-solves, Newton)
 // whose trip counts differ per lane, so a wave executes the union of all lanes' paths one after
 // the other.  Here every lane carries its stage in registers and each pass of the single wave-level
@@ -17,9 +17,6 @@
 #pragma once
 #include "mix_solver.hpp"
 
-#ifndef PCS_ROBUST_STAB_REJECT
-#define PCS_ROBUST_STAB_REJECT 1
-#endif
 
 namespace pcs {
 
@@ -27,12 +24,8 @@ constexpr double STAB_REJECT = -0.5;  // see BdLane::consume, R_BUBBLE
 // evaluations a robust second attempt may use (all drivers).  Rows it recovers need a bracketed root (~8) + a few Newton
 // iterations (bubble) resp. two pure roots + ~5 sweeps + ~8 Newton iterations (dew); rows without a solution would run
 // 200-350 evaluations each and, being few and scattered, make up the tail of the work-queue kernel
-#ifndef PCS_ROBUST_BUDGET_BUBBLE
-#define PCS_ROBUST_BUDGET_BUBBLE 48
-#endif
-#ifndef PCS_ROBUST_BUDGET_DEW
-#define PCS_ROBUST_BUDGET_DEW 96
-#endif
+constexpr int PCS_ROBUST_BUDGET_BUBBLE = 48;
+constexpr int PCS_ROBUST_BUDGET_DEW = 96;
 template <bool DEW> constexpr int robust_eval_budget() { return DEW ? PCS_ROBUST_BUDGET_DEW : PCS_ROBUST_BUDGET_BUBBLE; }
 
 // Per-lane solver state.  start() -> { point(); e = phase_eval(...); consume(e); } until done().
@@ -279,7 +272,7 @@ struct BdLane {
                 return;
             }
             if (r_for == R_BUBBLE) {
-                if (MODE != BD_MODE_INIT && robust && PCS_ROBUST_STAB_REJECT) {
+                if (MODE != BD_MODE_INIT && robust && 1) {
                     // the specified liquid must not lie deep inside a liquid-liquid spinodal: with M = d2(a + ideal)/drho_i drho_j,
                     // det M <= STAB_REJECT |M00 M11| gives the row up at once (a marginally unstable liquid, det M slightly
                     // negative, can still sit on a branch of the bubble curve that the iteration reaches: A/B on 50k rows with

@@ -13,36 +13,12 @@
 
 namespace pcs {
 
-#ifndef PCS_F32_TAYLOR_MAX
-#define PCS_F32_TAYLOR_MAX 1e-3f
-#endif
-#ifndef PCS_F32_LIQ_TAYLOR
-#define PCS_F32_LIQ_TAYLOR 1
-#endif
-#ifndef PCS_F32_VIRIAL
-#define PCS_F32_VIRIAL 1
-#endif
-#ifndef PCS_F32_PREDICT_STOP
-#define PCS_F32_PREDICT_STOP 1  // stop the fp32 iteration when the PREDICTED next step (quadratic convergence) is below the fp32 noise floor
-#endif
-#ifndef PCS_F32_PREDICT_TOL_L
-#define PCS_F32_PREDICT_TOL_L 5e-6f
-#endif
-#ifndef PCS_F32_PREDICT_TOL_V
-#define PCS_F32_PREDICT_TOL_V 5e-5f
-#endif
-#ifndef PCS_F32_PREDICT_CMAX
-#define PCS_F32_PREDICT_CMAX 1e3f
-#endif
-#ifndef PCS_F32_DENSE_RESTART
-#define PCS_F32_DENSE_RESTART 1
-#endif
-#ifndef PCS_F32_DENSE_LEVELS
-#define PCS_F32_DENSE_LEVELS 3  // restarts of the fp32 liquid root on the dense side (1 = eta 0.58 only)
-#endif
-#ifndef PCS_F32_LIQ_TOL
-#define PCS_F32_LIQ_TOL 1e-1f  // relative (scaled-Newton) step at which the fp32 liquid initialiser hands over to the coupled iteration
-#endif
+constexpr float PCS_F32_TAYLOR_MAX = 1e-3f;
+constexpr float PCS_F32_PREDICT_TOL_L = 5e-6f;
+constexpr float PCS_F32_PREDICT_TOL_V = 5e-5f;
+constexpr float PCS_F32_PREDICT_CMAX = 1e3f;
+constexpr int PCS_F32_DENSE_LEVELS = 3;  // restarts of the fp32 liquid root on the dense side (1 = eta 0.58 only)
+constexpr float PCS_F32_LIQ_TOL = 1e-1f;  // relative (scaled-Newton) step at which the fp32 liquid initialiser hands over to the coupled iteration
 
 struct F2 {  // value, d/drho, d2/drho2 in fp32
     float v, d1, d2;
@@ -160,10 +136,6 @@ PCS_DEV void pure_coef_f32(PureCoefF& f, const double* par, double T64) {
 
 struct EvalF { float a, p, dp, mu; };
 
-#ifndef PCS_F32_CLOSED
-#define PCS_F32_CLOSED 1
-#endif
-#if PCS_F32_CLOSED
 // Hard sphere, hard chain and dispersion of a pure component are a = rho F(eta) + rho^2 G(eta), eta = ceta rho, with
 //   F = m HS - (m-1) ln g,   HS = (4 eta - 3 eta^2) u^2,   g = (1 - eta/2) u^3,   u = 1/(1-eta)
 //   G = kd1 I1 + kd2 C I2,   C = 1/D,  D = 1 + m A - (m-1) B,  A = (8 eta - 2 eta^2) u^4,  B = poly u^2 w^2,  w = 1/(2-eta)
@@ -214,11 +186,7 @@ PCS_DEV F2 core_closed_f32(const PureCoefF& c, float rho) {
     a.d2 = ce * (2.0f * F1 + rc * F2_) + 2.0f * G + rc * (4.0f * G1 + rc * G2);
     return a;
 }
-#endif
 
-#ifndef PCS_ASSOC_CLOSED
-#define PCS_ASSOC_CLOSED 1
-#endif
 // Association term of a pure component in closed form (value, first and second density derivative).
 //   a_assoc = rho q(S),  q = na (ln XA - XA/2 + 1/2) + nb (ln XB - XB/2 + 1/2),  S = rho Delta(eta) = rho da h(eta),
 //   h = u + 1.5 eta u^2 + 0.5 eta^2 u^3,  u = 1/(1-eta)                                  (pcsaft_pure.py:163-176)
@@ -272,7 +240,6 @@ PCS_DEV F2 assoc_closed_f32(const PureCoefF& c, float rho) {
 
 // same model as pure_a() (pure_model.hpp), fp32
 PCS_DEV EvalF pure_eval_f32(const PureCoefF& c, float rho) {
-#if PCS_F32_CLOSED
     F2 a = core_closed_f32(c, rho);
     if (c.polar || c.assoc) {
         F2 r = f2(rho, 1.0f, 0.0f);
@@ -284,29 +251,7 @@ PCS_DEV EvalF pure_eval_f32(const PureCoefF& c, float rho) {
             a = a + (rho2 * c.qm) * ((J1 * J1) * recipf(J1 - r * J2));
         }
         if (c.assoc) {
-#if PCS_ASSOC_CLOSED
             a = a + assoc_closed_f32(c, rho);
-#else
-            F2 eta_m1 = recipf(1.0f - eta);
-            F2 k = eta * eta_m1;
-            F2 delta = (((k * ((k * 0.5f) + 1.5f)) + 1.0f) * eta_m1) * c.da;
-            F2 rhoa = r * c.na, rhob = r * c.nb;
-            F2 t = (rhob - rhoa) * delta;
-            F2 aux = 1.0f - t;
-            F2 sq = sqrtf2(aux * aux + (rhob * delta) * 4.0f);
-            F2 xa, xb;
-            if (t.v > 0.5f) {
-                xa = recipf(sq + t + 1.0f) * 2.0f;
-                xb = (sq + t + -1.0f) * recipf((rhob * delta) * 2.0f);
-            } else if (t.v < -0.5f) {
-                xa = (sq - t + -1.0f) * recipf((rhoa * delta) * 2.0f);
-                xb = recipf(sq - t + 1.0f) * 2.0f;
-            } else {
-                xa = recipf(sq + t + 1.0f) * 2.0f;
-                xb = recipf(sq - t + 1.0f) * 2.0f;
-            }
-            a = a + rhoa * (logf2(xa) - (xa * 0.5f) + 0.5f) + rhob * (logf2(xb) - (xb * 0.5f) + 0.5f);
-#endif
         }
     }
     EvalF ec;
@@ -315,56 +260,6 @@ PCS_DEV EvalF pure_eval_f32(const PureCoefF& c, float rho) {
     ec.dp = 1.0f + rho * a.d2;
     ec.mu = a.d1;
     return ec;
-#else
-    F2 r = f2(rho, 1.0f, 0.0f);
-    F2 eta = r * c.ceta;
-    F2 eta2 = eta * eta;
-    F2 om = 1.0f - eta;
-    F2 eta_m1 = recipf(om);
-    F2 eta_m2 = eta_m1 * eta_m1;
-    F2 hs = (r * c.m) * (((eta * 4.0f) - (eta2 * 3.0f)) * eta_m2);
-    F2 g = (1.0f - (eta * 0.5f)) * (eta_m1 * eta_m2);
-    F2 hc = (r * c.mm1) * logf2(g);
-    F2 I1 = hornerf<7>(c.ai, eta);
-    F2 I2 = hornerf<7>(c.bi, eta);
-    F2 eta_m4 = eta_m2 * eta_m2;
-    F2 t2 = eta_m1 * recipf(2.0f - eta);
-    F2 poly = eta * ((eta * ((eta * ((eta * -2.0f) + 12.0f)) + -27.0f)) + 20.0f);
-    F2 C1 = recipf((((eta * ((eta * -2.0f) + 8.0f)) * eta_m4) * c.m) - ((poly * (t2 * t2)) * c.mm1) + 1.0f);
-    F2 rho2 = r * r;
-    F2 a = hs - hc + rho2 * ((I1 * c.kd1) + ((C1 * I2) * c.kd2));
-    if (c.polar) {
-        F2 J1 = hornerf<5>(c.j1, eta);
-        F2 J2 = hornerf<4>(c.j2, eta);
-        a = a + (rho2 * c.qm) * ((J1 * J1) * recipf(J1 - r * J2));
-    }
-    if (c.assoc) {
-        F2 k = eta * eta_m1;
-        F2 delta = (((k * ((k * 0.5f) + 1.5f)) + 1.0f) * eta_m1) * c.da;
-        F2 rhoa = r * c.na, rhob = r * c.nb;
-        F2 t = (rhob - rhoa) * delta;
-        F2 aux = 1.0f - t;
-        F2 sq = sqrtf2(aux * aux + (rhob * delta) * 4.0f);
-        F2 xa, xb;
-        if (t.v > 0.5f) {
-            xa = recipf(sq + t + 1.0f) * 2.0f;
-            xb = (sq + t + -1.0f) * recipf((rhob * delta) * 2.0f);
-        } else if (t.v < -0.5f) {
-            xa = (sq - t + -1.0f) * recipf((rhoa * delta) * 2.0f);
-            xb = recipf(sq - t + 1.0f) * 2.0f;
-        } else {
-            xa = recipf(sq + t + 1.0f) * 2.0f;
-            xb = recipf(sq - t + 1.0f) * 2.0f;
-        }
-        a = a + rhoa * (logf2(xa) - (xa * 0.5f) + 0.5f) + rhob * (logf2(xb) - (xb * 0.5f) + 0.5f);
-    }
-    EvalF e;
-    e.a = a.v;
-    e.p = rho - a.v + rho * a.d1;
-    e.dp = 1.0f + rho * a.d2;
-    e.mu = a.d1;
-    return e;
-#endif
 }
 
 PCS_DEV bool finitef(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
@@ -386,7 +281,7 @@ PCS_DEV bool liquid_root_f32(const PureCoefF& f, float p_spec, float tol, float 
             EvalF e = pure_eval_f32(f, rl);
             n_eval++;
             float res = e.p - p_spec;
-            if (PCS_F32_DENSE_RESTART && it == first && it < PCS_F32_DENSE_LEVELS && finitef(e.p) && !(res > 0.0f)) {
+            if (it == first && it < PCS_F32_DENSE_LEVELS && finitef(e.p) && !(res > 0.0f)) {
                 // still on the dilute side of the root: next start 0.08 further up (eta = 0.58, 0.66, 0.74)
                 dense = true;
                 first = it + 1;
@@ -395,13 +290,9 @@ PCS_DEV bool liquid_root_f32(const PureCoefF& f, float p_spec, float tol, float 
                 ok = false;
                 done = true;
             } else {
-#ifdef PCS_LIQ_PLAIN_NEWTON
-                float step = res / e.dp;
-#else
                 float den = dense ? e.dp : e.dp - 4.0f * res * f.ceta * __builtin_amdgcn_rcpf(1.0f - rl * f.ceta);
                 float step = res * __builtin_amdgcn_rcpf(den);
                 if (!(den > 0.0f)) step = 2.0f * rl;  // -> rn < 0 -> this lane takes the fp64 initialiser
-#endif
                 float rn = rl - step;
                 if (!(rn > 0.0f)) { ok = false; done = true; }
                 else { done = fabsf(step) <= (dense ? tol_dense : tol) * rl; rl = rn; }
@@ -436,12 +327,8 @@ PCS_DEV void presolve_begin(const PureCoefF& f, PreState& s) {
     // zero-pressure liquid, handed over to the coupled iteration at a loose step
     bool ok = liquid_root_f32(f, 0.0f, PCS_F32_LIQ_TOL, 1e-2f, 12, s.rl, s.n_liq);
     const float rl = s.rl;
-#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 2  // timing experiments only
-    s.rv = ok ? 1.0f : 2.0f; s.l.a = s.l.p = s.l.mu = 0.0f; s.l.dp = 1.0f; s.ok = ok; s.done = true; return;
-#endif
     s.l = pure_eval_f32(f, rl);
     float rv = rl * f_exp(s.l.mu);
-#if PCS_F32_VIRIAL
     {
         // second-virial correction of the ideal-gas estimate: ln rho + 2 B rho = ln rho_L + mu_L^res with
         // B = lim a/rho^2 from the coefficients (no model evaluation); three scalar Newton steps
@@ -458,7 +345,6 @@ PCS_DEV void presolve_begin(const PureCoefF& f, PreState& s) {
         }
         if (finitef(r) && r > 0.0f) rv = r;
     }
-#endif
     s.code = !ok ? 1 : !finitef(rv) ? 6 : !(s.l.dp > 0.0f) ? 7 : !(rv < 0.5f * rl) ? 8 : !(rv > 1e-30f) ? 9 : 0;
     ok = ok && finitef(rv) && (s.l.dp > 0.0f) && (rv < 0.5f * rl) && (rv > 1e-30f);
     s.rv = rv;
@@ -492,16 +378,12 @@ PCS_DEV void presolve_coupled(const PureCoefF& f, PreState& s, int it_end) {
                 ok = false;
                 done = true;
             } else {
-#if PCS_F32_PREDICT_STOP
                 // quadratic convergence: |next step| ~ C step^2 with C estimated from the last two steps
                 float sl = fabsf(dl) * il, sv = fabsf(dv) * iv;
                 float pl = sl * sl * fminf(sl * __builtin_amdgcn_rcpf(sl_prev * sl_prev), PCS_F32_PREDICT_CMAX);
                 float pv = sv * sv * fminf(sv * __builtin_amdgcn_rcpf(sv_prev * sv_prev), PCS_F32_PREDICT_CMAX);
                 done = ((sl <= 2e-6f) && (sv <= 3e-5f)) || (n_cpl > 0 && sl < 1e-2f && sv < 1e-2f && pl <= PCS_F32_PREDICT_TOL_L && pv <= PCS_F32_PREDICT_TOL_V);
                 sl_prev = sl; sv_prev = sv;
-#else
-                done = (fabsf(dl) <= 2e-6f * rl) && (fabsf(dv) <= 3e-5f * rv);
-#endif
                 dl_taken = rln - rl;
                 rl = rln;
                 rv = rvn;
@@ -509,7 +391,6 @@ PCS_DEV void presolve_coupled(const PureCoefF& f, PreState& s, int it_end) {
             n_cpl++;
         }
         // the liquid state follows every taken step (also the last one of this call: a resumed lane starts from it)
-#if PCS_F32_LIQ_TAYLOR
         // the liquid barely moves after the first iteration: a lane whose liquid step was below 1e-3 carries its
         // liquid state to the new density by the Taylor expansion (a to 2nd, p to 1st order, dp kept) instead of a
         // re-evaluation; the error (~2.5 (dl/rho)^2 in the density) is below the fp32 noise the pass stops at.  The
@@ -528,9 +409,6 @@ PCS_DEV void presolve_coupled(const PureCoefF& f, PreState& s, int it_end) {
                 if (reeval) l = pure_eval_f32(f, rl);
             }
         }
-#else
-        if (act && !done) l = pure_eval_f32(f, rl);
-#endif
         if (__ballot(!done && n_cpl < it_end) == 0ull) break;
     }
     s.rl = rl; s.rv = rv; s.l = l; s.dpv = dpv_last; s.sl_prev = sl_prev; s.sv_prev = sv_prev;

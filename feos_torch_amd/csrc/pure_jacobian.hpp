@@ -13,15 +13,7 @@
 namespace pcs {
 
 constexpr int JAC_DIRS = 10;  // 8 parameters, T, p
-#ifndef PCS_JAC_CHUNK
-#define PCS_JAC_CHUNK 2
-#endif
-#ifndef PCS_JAC_BLOCKS
-#define PCS_JAC_BLOCKS 1  // 0: one DN<9> pass over the whole coefficient set
-#endif
-#ifndef PCS_JAC_ADJOINT
-#define PCS_JAC_ADJOINT 1  // closed-form coefficient adjoints + forward tangents of the coefficients only (0: tangents through everything)
-#endif
+constexpr int PCS_JAC_CHUNK = 2;
 constexpr int JAC_CHUNK = PCS_JAC_CHUNK;  // directions per pass
 
 // Adjoint of a(rho; c) with respect to the coefficient set at fixed density, in closed form (the expressions of the
@@ -143,7 +135,6 @@ template <int WHICH>
 PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv, double rl, double g[JAC_DIRS]) {
     typedef DN<double, JAC_CHUNK> G;
     constexpr int NPASS = (JAC_DIRS + JAC_CHUNK - 1) / JAC_CHUNK;
-#if PCS_JAC_ADJOINT
     {
         // Every property is  val = F(a_c(rho_V), a_c(rho_L), a'_c(rho_L); T, p)  with the densities fixed, so its parameter
         // derivative is  sum_k abar_k dc_k/dtheta + explicit T / p terms  with the coefficient adjoints abar from closed-form
@@ -198,7 +189,6 @@ PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv
                 adjoint_axpy(c0, adj, gl, wq * Kp * inv_l, [](const D1s& x) { return x.v; });
             }
         }
-#if PCS_JAC_BLOCKS
         // the coefficient set block by block, each with just its own inputs seeded (pure_model.hpp): core (m, sigma, eps, T)
         // DN<4>, dipole polynomials (m, sigma, eps, mu, T) DN<5>, association prefactor (sigma, kappa_ab, eps_ab, T) DN<4>;
         // the site counts enter directly
@@ -255,39 +245,10 @@ PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv
             g[6] += adj.na;
             g[7] += adj.nb;
         }
-#else
-        typedef DN<double, 9> G9;
-        G9 gp[8], gT;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            gp[k].v = par[k];
-#pragma unroll
-            for (int j = 0; j < 9; j++) gp[k].e[j] = (j == k) ? 1.0 : 0.0;
-        }
-        gT.v = T;
-#pragma unroll
-        for (int j = 0; j < 9; j++) gT.e[j] = (j == 8) ? 1.0 : 0.0;
-        PureCoef<G9> c;
-        pure_coef<G9>(c, gp, gT, true);
-        G9 S = c.m * adj.m + c.mm1 * adj.mm1 + c.ceta * adj.ceta + c.kd1 * adj.kd1 + c.kd2 * adj.kd2;
-#pragma unroll
-        for (int k = 0; k < 7; k++) S = S + c.ai[k] * adj.ai[k] + c.bi[k] * adj.bi[k];
-        if (c.polar) {
-            S = S + c.qm * adj.qm;
-#pragma unroll
-            for (int k = 0; k < 5; k++) S = S + c.j1[k] * adj.j1[k];
-#pragma unroll
-            for (int k = 0; k < 4; k++) S = S + c.j2[k] * adj.j2[k];
-        }
-        if (c.assoc) S = S + c.da * adj.da + c.na * adj.na + c.nb * adj.nb;
-#pragma unroll
-        for (int d = 0; d < 9; d++) g[d] = S.e[d];
-#endif
         g[8] += gT_explicit;
         g[9] = gP_explicit;
         return;
     }
-#endif
     double dp_plain = 1.0;
     if (WHICH != 0) {
         PureCoef<double> c0;

@@ -31,9 +31,7 @@ thread_local char pcs_abi::g_err[256] = "";
 
 namespace {
 
-#ifndef PCS_BLOCK
-#define PCS_BLOCK 256
-#endif
+constexpr int PCS_BLOCK = 256;
 constexpr int BLOCK = PCS_BLOCK;
 constexpr int ROW_PAD = 9;  // doubles per staged row (8 + 1 pad): bank-conflict-free per-lane reads
 
@@ -65,45 +63,13 @@ __device__ __forceinline__ void stage_params(const double* __restrict__ params, 
 // ------------------------------------------------------------------------------------------
 // waves per SIMD asked of the compiler for the all-fp64 instantiation (p_sat + densities): 210 VGPRs fit two; held to 128
 // (152 spill instructions) four are resident and the kernel is 1.20 -> 0.96 ms per 1e7 rows (three: 1.00 ms)
-#ifndef K1_WAVES
-#define K1_WAVES 4
-#endif
-#ifndef PCS_LITE_LDS_ROW
-#define PCS_LITE_LDS_ROW 1
-#endif
-#ifndef K1_WAVES_LITE
-#define K1_WAVES_LITE 4  // pressure-only instantiation: 122 VGPR, 4 waves per SIMD (without -fno-slp-vectorize: 168 VGPR, 3 waves)
-#endif
+constexpr int K1_WAVES = 4;
+constexpr int K1_WAVES_LITE = 4;  // pressure-only instantiation: 122 VGPR, 4 waves per SIMD (without -fno-slp-vectorize: 168 VGPR, 3 waves)
 constexpr int K1_BINS = 4;
-// PCS_K1_EXCHANGE = 1 (experiment, off): block-level straggler exchange of the fp32 coupled iteration (see the LITE branch
-// of k_pure_vle).  Measured on 1e7 rows: 0.797 ms without, 0.815 ms with it at 256 threads per workgroup, 0.834 ms at 512
-// (0.824 ms at 512 without), 1.014 ms at 1024 -- the two barriers and the serial straggler wave cost more than the
-// 1.4 iterations per wave they save.
-#ifndef PCS_K1_EXCHANGE
-#define PCS_K1_EXCHANGE 0
-#endif
-#ifndef K1_MAIN_ITS
-#define K1_MAIN_ITS 2
-#endif
-#if PCS_K1_EXCHANGE && defined(PCS_F32_PRESOLVE)
-// state of a parked lane (fp32 pre-solve not converged after K1_MAIN_ITS coupled iterations) + its staged row
-struct ParkedLane {
-    float v[9];
-    int meta;  // row (10 bits) | iteration count (6) | n_liq (8) | ok (1) | done (1)
-    __device__ __forceinline__ void put(const PreState& s, int row) {
-        v[0] = s.rl; v[1] = s.rv; v[2] = s.l.a; v[3] = s.l.p; v[4] = s.l.dp; v[5] = s.l.mu; v[6] = s.dpv; v[7] = s.sl_prev; v[8] = s.sv_prev;
-        meta = row | (s.it << 10) | (s.n_liq << 16) | ((s.ok ? 1 : 0) << 24) | ((s.done ? 1 : 0) << 25);
-    }
-    __device__ __forceinline__ int get(PreState& s) const {
-        s.rl = v[0]; s.rv = v[1]; s.l.a = v[2]; s.l.p = v[3]; s.l.dp = v[4]; s.l.mu = v[5]; s.dpv = v[6]; s.sl_prev = v[7]; s.sv_prev = v[8];
-        s.it = (meta >> 10) & 63; s.n_liq = (meta >> 16) & 255; s.ok = (meta >> 24) & 1; s.done = (meta >> 25) & 1; s.code = 0;
-        return meta & 1023;
-    }
-};
-#else
-#undef PCS_K1_EXCHANGE
-#define PCS_K1_EXCHANGE 0
-#endif
+// (Round 2 measured a block-level straggler exchange of the fp32 coupled iteration -- lanes not converged after two iterations
+// parked in LDS and finished together by the first wave: 0.815 ms against 0.797 ms without it at 256 threads per workgroup,
+// 0.834 ms at 512, 1.014 ms at 1024; the two barriers and the serial straggler wave cost more than the 1.4 iterations per
+// wave they save.  Removed.)
 
 // Bucket key of a staged row: model class (which branches of the Helmholtz energy the row needs) in
 // Gray order none, polar, polar+assoc, assoc -- neighbouring buckets share a branch.  Lanes of one
@@ -130,10 +96,6 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
     __shared__ double lds[BLOCK * ROW_PAD];  // 8 parameters + T per row
     __shared__ int perm[BLOCK];
     __shared__ int bins[K1_BINS];
-#if PCS_K1_EXCHANGE
-    __shared__ ParkedLane parked[LITE ? BLOCK : 1];
-    __shared__ int n_parked;
-#endif
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
     // cooperative, coalesced staging (rows past n clamp to row n-1; never stored)
@@ -153,9 +115,6 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
         const int64_t g = row0 + t;
         lds[t * ROW_PAD + 8] = temp[g < n ? g : n - 1];
         if (t < K1_BINS) bins[t] = 0;
-#if PCS_K1_EXCHANGE
-        if (t == 0) n_parked = 0;
-#endif
     }
     __syncthreads();
     const int key = k1_bucket(&lds[t * ROW_PAD]);
@@ -184,61 +143,13 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
 
     VleResult res;
     int st;  // wave-uniform calls
-#if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
-#if PCS_K1_EXCHANGE
-    if (LITE) {
-        // fp32 pre-solve with the block-level straggler exchange: every wave runs at most K1_MAIN_ITS coupled iterations
-        // (92 % of the lanes need exactly two); lanes that are not converged then park their state in LDS, and the
-        // parked lanes of the whole workgroup are finished together -- 64 at a time, by the first wave(s) -- instead of
-        // every wave iterating on for its few slow lanes (3.4 iterations per wave against 2.1 per lane).  A parked
-        // lane's iteration continues from its own state with coefficients recomputed from its staged row: its result
-        // does not depend on which lanes it shares a wave with.
-        const double* row = &lds[r * ROW_PAD];
-        PreState ps;
-        {
-            PureCoefF cf;
-            pure_coef_f32(cf, row, T);
-            presolve_begin(cf, ps);
-            presolve_coupled(cf, ps, K1_MAIN_ITS);
-        }
-        int slot = -1;
-        if (ps.ok && !ps.done) {
-            slot = atomicAdd(&n_parked, 1);
-            parked[slot].put(ps, r);
-        }
-        __syncthreads();
-        const int np = n_parked;
-        for (int k = t; k < ((np + 63) & ~63); k += BLOCK) {  // whole waves: the loops inside are wave-uniform
-            PreState q;
-            PureCoefF cf;
-            int rq = 0;
-            const bool have = k < np;
-            if (have) rq = parked[k].get(q);
-            else { q.ok = false; q.done = true; q.it = 0; q.rl = q.rv = 1.0f; q.l.a = q.l.p = q.l.mu = 0.0f; q.l.dp = 1.0f; q.dpv = 1.0f; q.sl_prev = q.sv_prev = 1.0f; q.n_liq = q.code = 0; }
-            pure_coef_f32(cf, &lds[rq * ROW_PAD], lds[rq * ROW_PAD + 8]);
-            presolve_coupled(cf, q, 8);
-            if (have) parked[k].put(q, rq);
-        }
-        __syncthreads();
-        if (slot >= 0) parked[slot].get(ps);
-        st = vle_lite_finish(row, T, ps.ok, (double)ps.rl, (double)ps.rv, ps.l.dp, ps.dpv, res);
-#ifdef PCS_DIAG_ITERS
-        res.iters |= (ps.n_liq | (ps.it << 8) | (ps.code << 16)) << 8;
-#endif
-    }
-#elif PCS_LITE_LDS_ROW
+#ifdef PCS_F32_PRESOLVE
     if (LITE) st = vle_fast_lite(&lds[r * ROW_PAD], lds[r * ROW_PAD + 8], res);  // the row is re-read from LDS for the fp64 coefficients
-#else
-    if (LITE) st = vle_fast_lite(par, T, res);
-#endif
     else st = rho_eq ? vle_fast<true>(par, T, res, 1e-8, TOL_STEP) : vle_fast<true>(par, T, res);
 #else
     st = rho_eq ? vle_fast<false>(par, T, res, 1e-8, TOL_STEP) : vle_fast<false>(par, T, res);
 #endif
 
-#ifdef PCS_FORCE_RETRY  // test builds: send every row through the robust pass
-    st = ST_RETRY;
-#endif
     if (!live) return;
     if (st == ST_OK) {
         if (p_sat) p_sat[i] = res.p_star * T * P_UNIT;
@@ -299,15 +210,8 @@ __global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restri
 // ------------------------------------------------------------------------------------------
 // liquid-density kernel: 204 VGPRs fit two waves per SIMD; held to 168 (52 spill instructions) three: 1.02 -> 0.89 ms per 1e7
 // rows (four, 128 VGPRs: 1.02 ms)
-#ifndef K4_WAVES
-#define K4_WAVES 2  // Jacobian kernels: two (256 VGPRs); held to 168 for three they spill inside the DN<9> pass: 0.89 -> 2.24 ms
-#endif
-#ifndef K2_WAVES
-#define K2_WAVES 3
-#endif
-#ifndef PCS_K2_BUCKET
-#define PCS_K2_BUCKET 1  // A/B 1e7 rows: 1.34 -> 1.22 ms
-#endif
+constexpr int K4_WAVES = 2;  // Jacobian kernels: two (256 VGPRs); held to 168 for three they spill inside the DN<9> pass: 0.89 -> 2.24 ms
+constexpr int K2_WAVES = 3;
 __global__ __launch_bounds__(BLOCK, K2_WAVES) void k_pure_liquid_density(const double* __restrict__ params,
                                                                const double* __restrict__ temp,
                                                                const double* __restrict__ pressure, int64_t n,
@@ -317,7 +221,6 @@ __global__ __launch_bounds__(BLOCK, K2_WAVES) void k_pure_liquid_density(const d
     __shared__ double lds[BLOCK * ROW_PAD];
     const int64_t row0 = (int64_t)blockIdx.x * BLOCK;
     double par[8];
-#if PCS_K2_BUCKET
     // rows of the workgroup bucketed by class as in k_pure_vle (LDS counting sort): a wave mostly runs one set of
     // branches of the Helmholtz energy
     __shared__ int perm[BLOCK];
@@ -344,10 +247,6 @@ __global__ __launch_bounds__(BLOCK, K2_WAVES) void k_pure_liquid_density(const d
 #pragma unroll
     for (int q = 0; q < 8; q++) par[q] = lds[src * ROW_PAD + q];
     const int64_t i = row0 + src;
-#else
-    const int64_t i = row0 + threadIdx.x;
-    stage_params(params, n, row0, lds, par);
-#endif
     const bool live = i < n;
     const int64_t ii = live ? i : n - 1;
     const double T = temp[ii];
@@ -395,9 +294,6 @@ __global__ __launch_bounds__(BLOCK) void k_pure_derivatives(const double* __rest
 // ------------------------------------------------------------------------------------------
 // K4: Jacobian of a property w.r.t. (8 parameters, T, p) at fixed densities
 // ------------------------------------------------------------------------------------------
-#ifndef PCS_K4_BUCKET
-#define PCS_K4_BUCKET 1
-#endif
 template <int WHICH>
 __global__ __launch_bounds__(BLOCK, K4_WAVES) void k_pure_jacobian(const double* __restrict__ params,
                                                          const double* __restrict__ temp,
@@ -411,7 +307,7 @@ __global__ __launch_bounds__(BLOCK, K4_WAVES) void k_pure_jacobian(const double*
     double par[8];
     // class bucketing as in k_pure_vle for the two liquid-density properties (A/B on 1e7 rows: 4.0 -> 3.9 ms and
     // 12.0 -> 8.4 ms; the vapour-pressure Jacobian gets slightly slower with it, 3.5 -> 3.7 ms, and keeps the row order)
-    constexpr bool BUCKET = PCS_K4_BUCKET && WHICH != 0;
+    constexpr bool BUCKET = WHICH != 0;
     __shared__ int perm[BUCKET ? BLOCK : 1];
     __shared__ int bins[K1_BINS];
     const int t = threadIdx.x;
@@ -523,7 +419,7 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
     if (int ez = zero_ints(retry, 1, s)) return ez;
     hipError_t e;
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
-#if defined(PCS_F32_PRESOLVE) && PCS_LITE_FINISH
+#ifdef PCS_F32_PRESOLVE
     // main kernel (lean: rows without an fp32 pre-solve go to the list with bit 31 set) + all-fp64 fallback kernel.
     // LITE only for the pressure-only call: its densities are converged to ~1e-9 (enough for p*, whose error is of
     // second order in them), while rho_eq and the Jacobian kernels (rho_vl) want the ~1e-12 of the D2 finish.

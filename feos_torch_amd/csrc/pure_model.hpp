@@ -268,13 +268,6 @@ PCS_DEV R pure_a(const PureCoef<P>& c, const R& rho) {
     return a;
 }
 
-#ifndef PCS_D1S_CLOSED
-#define PCS_D1S_CLOSED 1
-#endif
-#ifndef PCS_ASSOC_CLOSED64
-#define PCS_ASSOC_CLOSED64 1  // closed-form association term in the fp64 finish (value + first derivative)
-#endif
-#if PCS_D1S_CLOSED
 // The pressure-only fp64 finish (R = D1s: a and a') with hard sphere, chain and dispersion in closed form, as the fp32
 // pre-solve does (pure_f32.hpp): a = rho F(eta) + rho^2 G(eta),
 //   F = m HS - (m-1) ln g,  HS = (4 eta - 3 eta^2) u^2,  HS' = (4 - 2 eta) u^3,  (ln g)' = 3u - w,  u = 1/(1-eta), w = 1/(2-eta)
@@ -308,7 +301,6 @@ PCS_DEV D1s pure_a<double, D1s>(const PureCoef<double>& c, const D1s& rho) {
             a = a + ((rho * rho) * c.qm) * ((J1 * J1) * d_recip(J1 - rho * J2));
         }
         if (c.assoc) {
-#if PCS_ASSOC_CLOSED64
             // closed form, value and first derivative (see assoc_closed_f32, pure_f32.hpp): a_assoc = rho q(S),
             // a' = q + rho q_S S',  q_S = -na nb XA XB (the energy is stationary in the site fractions), S = rho da h(eta)
             const double u_ = d_recip(1.0 - eta), eu = eta * u_;
@@ -331,29 +323,6 @@ PCS_DEV D1s pure_a<double, D1s>(const PureCoef<double>& c, const D1s& rho) {
             const double q = c.na * (d_log(xa) - 0.5 * xa + 0.5) + c.nb * (d_log(xb) - 0.5 * xb + 0.5);
             const double q1 = -(c.na * c.nb) * (xa * xb);
             a = a + D1s(r * q, (q + r * q1 * S1) * rho.d1);
-#else
-            D1s eta_m1 = d_recip(1.0 - eta_d);
-            D1s k = eta_d * eta_m1;
-            D1s delta = ((1.0 + k * (1.5 + 0.5 * k)) * eta_m1) * c.da;
-            D1s rhoa = rho * c.na;
-            D1s rhob = rho * c.nb;
-            D1s t = (rhob - rhoa) * delta;
-            D1s aux = 1.0 - t;
-            D1s sq = d_sqrt(aux * aux + 4.0 * (rhob * delta));
-            D1s xa, xb;  // conjugate forms, see pure_a above
-            const double tr = re(t);
-            if (tr > 0.5) {
-                xa = 2.0 * d_recip(sq + 1.0 + t);
-                xb = (sq - 1.0 + t) * d_recip(2.0 * (rhob * delta));
-            } else if (tr < -0.5) {
-                xa = (sq - 1.0 - t) * d_recip(2.0 * (rhoa * delta));
-                xb = 2.0 * d_recip(sq + 1.0 - t);
-            } else {
-                xa = 2.0 * d_recip(sq + 1.0 + t);
-                xb = 2.0 * d_recip(sq + 1.0 - t);
-            }
-            a = a + rhoa * site_term(xa) + rhob * site_term(xb);
-#endif
         }
     }
     return a;
@@ -424,6 +393,5 @@ PCS_DEV D2<double> pure_a<double, D2<double>>(const PureCoef<double>& c, const D
     }
     return a;
 }
-#endif
 
 }  // namespace pcs

@@ -46,9 +46,6 @@ PCS_DEV Eval pure_eval_mu(const PureCoef<double>& c, double rho, double& mu_res)
     return e;
 }
 
-#ifndef PCS_LITE_FINISH
-#define PCS_LITE_FINISH 1
-#endif
 constexpr int LIQ_MAX_IT = 40;
 constexpr int LITE_MAX_IT = 3;
 constexpr int VLE_MAX_IT = 40;
@@ -96,9 +93,7 @@ PCS_DEV int liquid_newton(const PureCoef<double>& c, double p_spec, double tol, 
     return (done && !fail) ? ST_OK : ST_FAILED;
 }
 
-#ifndef PCS_K2_F32_TOL
-#define PCS_K2_F32_TOL 1e-4f
-#endif
+constexpr float PCS_K2_F32_TOL = 1e-4f;
 // Liquid density at (T, p): fp32 root (pure_f32.hpp) to its noise floor, then the fp64 Newton of
 // pcsaft_pure.py:196-199 from there (typically one evaluation).  Lanes whose fp32 pass misbehaves
 // start from eta = 0.5 in fp64.
@@ -189,27 +184,10 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
     pure_coef_f32(cf, par, T);
 #endif
 #ifdef PCS_F32_PRESOLVE
-#ifdef PCS_DIAG_ITERS
-    int diag = 0;
-    warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32, &diag);
-#else
-#if !(defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 1)
     warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32);  // fp32 initialiser + first iterations (pure_f32.hpp)
-#endif
-#endif
 #endif
     PureCoef<double> c;
     pure_coef<double>(c, par, T, false);
-#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT <= 3  // timing experiments only: stop after coef (1), fp32 liquid (2), fp32 pre-solve (3)
-    {
-        double acc = rl + rv + c.m + c.mm1 + c.ceta + c.kd1 + c.kd2 + c.da + c.na + c.nb + c.qm;
-        for (int i = 0; i < 7; i++) acc += c.ai[i] + c.bi[i];
-        for (int i = 0; i < 5; i++) acc += c.j1[i];
-        for (int i = 0; i < 4; i++) acc += c.j2[i];
-        out.p_star = acc; out.rho_l = rl; out.rho_v = rv; out.iters = 0;
-        return ST_OK;
-    }
-#endif
     bool active = warm;
     if (!LEAN && __ballot(!warm) != 0ull) {
         // lanes without a usable fp32 result: fp64 zero-pressure liquid (the others idle through it)
@@ -230,10 +208,6 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
         // (a warm lane carries a converged fp32 vapour density instead: only sanity-checked)
         if (!is_finite_bits(rv) || !(rv < (warm ? 0.7 : 0.05) * rl)) active = false;
     }
-#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 4  // timing experiments only: stop after the first fp64 liquid evaluation
-    out.p_star = l.p + l.dp + l.a + rv; out.rho_l = rl; out.rho_v = rv; out.iters = 0;
-    return active ? ST_OK : ST_RETRY;
-#endif
     bool done = false;
     out.iters = 0;
     for (int it = 0; it < VLE_MAX_IT; it++) {
@@ -258,9 +232,6 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
         if (__ballot(active && !done) == 0ull) break;
         if (active && !done) l = pure_eval(c, rl);
     }
-#if defined(PCS_DIAG_ITERS) && defined(PCS_F32_PRESOLVE)
-    out.iters |= diag << 8;
-#endif
     if (LEAN && !warm) return ST_FALLBACK;
     if (done && out.rho_v < 0.7 * out.rho_l && vapour_is_physical(out.p_star, out.rho_v)) return ST_OK;
     return ST_RETRY;  // includes cap hit and near-critical states: let the robust path decide
@@ -276,16 +247,8 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
 // block-level straggler exchange in between.
 PCS_DEV int vle_lite_finish(const double* par, double T, bool warm, double rl, double rv, float dpl32, float dpv32,
                             VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
-#if defined(PCS_STAGE_CUT) && (PCS_STAGE_CUT == 2 || PCS_STAGE_CUT == 3)  // timing experiments (scripts/dev/stage_time.py): after the fp32 liquid root (2, cut inside the pre-solve) / the whole pre-solve (3)
-    out.p_star = rl + rv + (double)(dpl32 + dpv32); out.rho_l = rl; out.rho_v = rv; out.iters = 0;
-    return warm ? ST_OK : ST_FALLBACK;
-#endif
     PureCoef<double> c;
     pure_coef<double>(c, par, T, false);
-#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 4  // + fp64 coefficients
-    out.p_star = rl + rv + c.ceta + c.kd2 + c.ai[3] + c.bi[5] + c.j1[2] + c.j2[1] + c.da; out.rho_l = rl; out.rho_v = rv; out.iters = 0;
-    return warm ? ST_OK : ST_FALLBACK;
-#endif
     bool active = warm && is_finite_bits(rv) && (rv < 0.7 * rl) && (dpl32 > 0.0f) && (dpv32 > 0.0f);
     bool done = false;
     out.iters = 0;
@@ -332,20 +295,8 @@ PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double to
     float dpl32 = 1.0f, dpv32 = 1.0f;
     PureCoefF cf;
     pure_coef_f32(cf, par, T);
-#if defined(PCS_STAGE_CUT) && PCS_STAGE_CUT == 1  // timing experiments only: fp32 coefficients
-    out.p_star = (double)(cf.ceta + cf.kd2 + cf.ai[3] + cf.bi[5] + cf.j1[2] + cf.j2[1] + cf.da); out.rho_l = out.rho_v = 1.0; out.iters = 0;
-    return ST_OK;
-#endif
-#ifdef PCS_DIAG_ITERS
-    int diag = 0;
-    const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32, &diag);
-    const int st = vle_lite_finish(par, T, warm, rl, rv, dpl32, dpv32, out, tol_l, tol_v);
-    out.iters |= diag << 8;
-    return st;
-#else
     const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32);
     return vle_lite_finish(par, T, warm, rl, rv, dpl32, dpv32, out, tol_l, tol_v);
-#endif
 }
 #endif
 

@@ -127,32 +127,98 @@ struct Encoder {
     }
 };
 
+// shared front half of both entry points: identifier table
+bool load_identifiers(Encoder& enc, PyObject* ident) {
+    PyObject* fi = PySequence_Fast(ident, "segment_identifier must be a sequence of str");
+    if (!fi) return false;
+    const Py_ssize_t S = PySequence_Fast_GET_SIZE(fi);
+    if (S > 255) {
+        Py_DECREF(fi);
+        PyErr_SetString(PyExc_ValueError, "at most 255 segment types (uint8 row encoding)");
+        return false;
+    }
+    for (Py_ssize_t k = 0; k < S; k++) {
+        PyObject* s = PySequence_Fast_GET_ITEM(fi, k);
+        Py_ssize_t len = 0;
+        const char* u = PyUnicode_Check(s) ? PyUnicode_AsUTF8AndSize(s, &len) : nullptr;
+        if (!u) {
+            Py_DECREF(fi);
+            if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "segment identifiers must be str");
+            return false;
+        }
+        enc.by_name[std::string(u, (size_t)len)] = (int)k;  // later duplicates win, like the dict of the specification
+    }
+    Py_DECREF(fi);
+    return true;
+}
+
+// Walks the rows and hands `sink(row, component, encoding, id)` every molecule: id = running number of the distinct
+// (segments, bonds) object pair, encoding = its 40 bytes.  Batches draw their molecules from a small library and re-use the
+// same list objects (the reference's tests build their rows that way): a molecule is encoded ONCE per distinct pair, and a row
+// costs two probes of a direct-mapped pointer cache in front of the hash map.
+template <class Sink>
+bool walk_rows(Encoder& enc, PyObject* fs, PyObject* fb, Py_ssize_t n, std::vector<const Enc*>& unique, Sink&& sink) {
+    constexpr size_t CACHE = 4096;
+    struct Slot { PyObject *segs, *bonds; const Enc* e; int id; };
+    std::vector<Slot> cache(CACHE, Slot{nullptr, nullptr, nullptr, -1});
+    std::unordered_map<const Enc*, int> ids;
+    PyObject** seg_rows = PySequence_Fast_ITEMS(fs);
+    PyObject** bond_rows = PySequence_Fast_ITEMS(fb);
+    bool ok = true;
+    for (Py_ssize_t r = 0; ok && r < n; r++) {
+        PyObject *row_s = seg_rows[r], *row_b = bond_rows[r];
+        PyObject *rs = nullptr, *rb = nullptr;  // owned only on the generic path
+        PyObject *mol_s[2], *mol_b[2];
+        if (PyList_CheckExact(row_s) && PyList_CheckExact(row_b) && PyList_GET_SIZE(row_s) == 2 && PyList_GET_SIZE(row_b) == 2) {
+            mol_s[0] = PyList_GET_ITEM(row_s, 0); mol_s[1] = PyList_GET_ITEM(row_s, 1);
+            mol_b[0] = PyList_GET_ITEM(row_b, 0); mol_b[1] = PyList_GET_ITEM(row_b, 1);
+        } else {
+            rs = PySequence_Fast(row_s, "a row of segment_lists must hold two molecules");
+            rb = rs ? PySequence_Fast(row_b, "a row of bond_lists must hold two molecules") : nullptr;
+            if (!rs || !rb || PySequence_Fast_GET_SIZE(rs) != 2 || PySequence_Fast_GET_SIZE(rb) != 2) {
+                if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "each row must hold two molecules");
+                ok = false;
+            } else {
+                for (int c = 0; c < 2; c++) { mol_s[c] = PySequence_Fast_GET_ITEM(rs, c); mol_b[c] = PySequence_Fast_GET_ITEM(rb, c); }
+            }
+        }
+        for (int c = 0; ok && c < 2; c++) {
+            PyObject *segs = mol_s[c], *bonds = mol_b[c];
+            Slot& slot = cache[((reinterpret_cast<uintptr_t>(segs) >> 4) * 0x9E3779B97F4A7C15ull ^ (reinterpret_cast<uintptr_t>(bonds) >> 4)) % CACHE];
+            if (!(slot.segs == segs && slot.bonds == bonds)) {
+                const Enc* e;
+                auto it = enc.by_lists.find({segs, bonds});
+                if (it != enc.by_lists.end()) {
+                    e = &it->second;
+                } else {
+                    Enc fresh;
+                    if (!enc.molecule(segs, bonds, fresh)) { ok = false; break; }
+                    e = &enc.by_lists.emplace(std::make_pair(segs, bonds), fresh).first->second;  // (node-based map: stable addresses)
+                }
+                auto jt = ids.find(e);
+                int id;
+                if (jt == ids.end()) {
+                    id = (int)unique.size();
+                    unique.push_back(e);
+                    ids.emplace(e, id);
+                } else {
+                    id = jt->second;
+                }
+                slot = Slot{segs, bonds, e, id};
+            }
+            sink(r, c, slot.e, slot.id);
+        }
+        Py_XDECREF(rs);
+        Py_XDECREF(rb);
+    }
+    return ok;
+}
+
 PyObject* encode_rows(PyObject*, PyObject* args) {
     PyObject *ident, *seg_lists, *bond_lists, *out_obj;
     if (!PyArg_ParseTuple(args, "OOOO", &ident, &seg_lists, &bond_lists, &out_obj)) return nullptr;
     Encoder enc;
-    {
-        PyObject* fi = PySequence_Fast(ident, "segment_identifier must be a sequence of str");
-        if (!fi) return nullptr;
-        const Py_ssize_t S = PySequence_Fast_GET_SIZE(fi);
-        if (S > 255) {
-            Py_DECREF(fi);
-            PyErr_SetString(PyExc_ValueError, "at most 255 segment types (uint8 row encoding)");
-            return nullptr;
-        }
-        for (Py_ssize_t k = 0; k < S; k++) {
-            PyObject* s = PySequence_Fast_GET_ITEM(fi, k);
-            Py_ssize_t len = 0;
-            const char* u = PyUnicode_Check(s) ? PyUnicode_AsUTF8AndSize(s, &len) : nullptr;
-            if (!u) {
-                Py_DECREF(fi);
-                if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "segment identifiers must be str");
-                return nullptr;
-            }
-            enc.by_name[std::string(u, (size_t)len)] = (int)k;  // later duplicates win, like the dict of the specification
-        }
-        Py_DECREF(fi);
-    }
+    if (!load_identifiers(enc, ident)) return nullptr;
     Py_buffer view;
     if (PyObject_GetBuffer(out_obj, &view, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) return nullptr;
     PyObject* fs = PySequence_Fast(seg_lists, "segment_lists must be a sequence");
@@ -167,35 +233,17 @@ PyObject* encode_rows(PyObject*, PyObject* args) {
             PyErr_SetString(PyExc_ValueError, "output buffer must hold n*80 bytes");
             ok = false;
         }
-        uint8_t* rows = static_cast<uint8_t*>(view.buf);
-        for (Py_ssize_t r = 0; ok && r < n; r++) {
-            PyObject* rs = PySequence_Fast(PySequence_Fast_GET_ITEM(fs, r), "a row of segment_lists must hold two molecules");
-            PyObject* rb = rs ? PySequence_Fast(PySequence_Fast_GET_ITEM(fb, r), "a row of bond_lists must hold two molecules") : nullptr;
-            if (!rs || !rb || PySequence_Fast_GET_SIZE(rs) != 2 || PySequence_Fast_GET_SIZE(rb) != 2) {
-                if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "each row must hold two molecules");
-                ok = false;
-            }
-            for (int c = 0; ok && c < 2; c++) {
-                PyObject* segs = PySequence_Fast_GET_ITEM(rs, c);
-                PyObject* bonds = PySequence_Fast_GET_ITEM(rb, c);
-                const Enc* e;
-                auto it = enc.by_lists.find({segs, bonds});
-                if (it != enc.by_lists.end()) {
-                    e = &it->second;
-                } else {
-                    Enc fresh;
-                    if (!enc.molecule(segs, bonds, fresh)) { ok = false; break; }
-                    e = &enc.by_lists.emplace(std::make_pair(segs, bonds), fresh).first->second;
-                }
+        if (ok) {
+            uint8_t* rows = static_cast<uint8_t*>(view.buf);
+            std::vector<const Enc*> unique;
+            ok = walk_rows(enc, fs, fb, n, unique, [rows](Py_ssize_t r, int c, const Enc* e, int) {
                 uint8_t* row = rows + r * 80;
                 std::memcpy(row + 8 * c, e->b, 8);
                 std::memcpy(row + 16 + 8 * c, e->b + 8, 8);
                 std::memcpy(row + 32 + 8 * c, e->b + 16, 8);
                 std::memcpy(row + 48 + 8 * c, e->b + 24, 8);
                 std::memcpy(row + 64 + 8 * c, e->b + 32, 8);
-            }
-            Py_XDECREF(rs);
-            Py_XDECREF(rb);
+            });
         }
     }
     Py_XDECREF(fs);
@@ -205,9 +253,52 @@ PyObject* encode_rows(PyObject*, PyObject* args) {
     Py_RETURN_NONE;
 }
 
+// encode_indices(segment_identifier, segment_lists, bond_lists, index_out) -> bytes
+//   index_out: writable C-contiguous int32 buffer [n, 2]: for every row and component the number of its molecule in the
+//   returned table; the table holds 40 bytes per DISTINCT molecule (seg_id[8], seg_cnt[8], bond_a[8], bond_b[8],
+//   bond_cnt[8]).  The 80-byte rows are assembled from the two on the device (feos_torch_amd.gc_pcsaft.encode_rows_device):
+//   the host writes 8 bytes per row instead of 80.
+PyObject* encode_indices(PyObject*, PyObject* args) {
+    PyObject *ident, *seg_lists, *bond_lists, *out_obj;
+    if (!PyArg_ParseTuple(args, "OOOO", &ident, &seg_lists, &bond_lists, &out_obj)) return nullptr;
+    Encoder enc;
+    if (!load_identifiers(enc, ident)) return nullptr;
+    Py_buffer view;
+    if (PyObject_GetBuffer(out_obj, &view, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) return nullptr;
+    PyObject* fs = PySequence_Fast(seg_lists, "segment_lists must be a sequence");
+    PyObject* fb = fs ? PySequence_Fast(bond_lists, "bond_lists must be a sequence") : nullptr;
+    bool ok = fs && fb;
+    std::vector<const Enc*> unique;
+    if (ok) {
+        const Py_ssize_t n = PySequence_Fast_GET_SIZE(fs);
+        if (PySequence_Fast_GET_SIZE(fb) != n) {
+            PyErr_SetString(PyExc_ValueError, "segment_lists and bond_lists differ in length");
+            ok = false;
+        } else if (view.len != n * 8) {
+            PyErr_SetString(PyExc_ValueError, "index buffer must hold n*2 int32");
+            ok = false;
+        }
+        if (ok) {
+            int32_t* idx = static_cast<int32_t*>(view.buf);
+            ok = walk_rows(enc, fs, fb, n, unique, [idx](Py_ssize_t r, int c, const Enc*, int id) { idx[2 * r + c] = id; });
+        }
+    }
+    Py_XDECREF(fs);
+    Py_XDECREF(fb);
+    PyBuffer_Release(&view);
+    if (!ok) return nullptr;
+    PyObject* table = PyBytes_FromStringAndSize(nullptr, (Py_ssize_t)unique.size() * 40);
+    if (!table) return nullptr;
+    char* dst = PyBytes_AS_STRING(table);
+    for (size_t k = 0; k < unique.size(); k++) std::memcpy(dst + 40 * k, unique[k]->b, 40);
+    return table;
+}
+
 PyMethodDef methods[] = {
     {"encode_rows", encode_rows, METH_VARARGS,
      "encode_rows(segment_identifier, segment_lists, bond_lists, out) -> None; fills out [n, 80] uint8"},
+    {"encode_indices", encode_indices, METH_VARARGS,
+     "encode_indices(segment_identifier, segment_lists, bond_lists, index_out[n,2] int32) -> bytes (40 per distinct molecule)"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_gc_encode", "native gc-PC-SAFT row encoder", -1, methods,

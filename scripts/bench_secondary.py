@@ -54,8 +54,12 @@ if "4" in which:
 if "5" in which:
     n = 1_000_000
     table = load_segment_table(os.path.join(ROOT, "tests", "data", "sauer2014_hetero.json"))
-    t0 = time.time(); b = gc_batch(n, table); ident = [s for s, _ in table]
-    rows = d(encode_rows(ident, b["segment_lists"], b["bond_lists"])); t_enc = time.time() - t0
+    b = gc_batch(n, table); ident = [s for s, _ in table]
+    from feos_torch_amd.gc_pcsaft import encode_rows_device
+    encode_rows_device(ident, b["segment_lists"][:1000], b["bond_lists"][:1000], "cuda")  # warm (allocator, kernels)
+    torch.cuda.synchronize()
+    t0 = time.time(); rows = encode_rows_device(ident, b["segment_lists"], b["bond_lists"], "cuda"); torch.cuda.synchronize()
+    t_enc = time.time() - t0  # host encoding of the distinct molecules + row indices, H2D of 8 B per row, row assembly on the GPU
     seg = torch.tensor(np.stack([v for _, v in table]), dtype=torch.float64)
     kab = torch.zeros((len(ident), len(ident)), dtype=torch.float64)
     for s1, s2, k in b["kab_list"]:

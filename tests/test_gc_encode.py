@@ -3,6 +3,7 @@ specification `encode_rows_py` and against the oracle's own encoder.  CPU only."
 import os
 
 import numpy as np
+import torch
 import pytest
 
 from conftest import ROOT
@@ -133,3 +134,25 @@ def test_class_order_is_a_permutation_sorted_by_class():
     k = key[order.numpy()]
     assert np.all(k[:-1] >= k[1:])
     assert len(np.unique(key)) >= 3  # the synthetic library really mixes classes
+
+
+def test_index_encoding_assembles_the_same_rows():
+    """encode_indices (distinct molecules once + two int32 per row) + the gather of encode_rows_device give the rows of the
+    host encoder byte for byte (cpu device here; the GPU path is the same torch gather)."""
+    import os
+
+    from feos_torch_amd.gc_pcsaft import encode_rows, encode_rows_device
+    from feos_torch_amd.synthetic import gc_batch, load_segment_table
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = load_segment_table(os.path.join(root, "tests", "data", "sauer2014_hetero.json"))
+    b = gc_batch(5000, table, seed=5)
+    ident = [s for s, _ in table]
+    rows = encode_rows_device(ident, b["segment_lists"], b["bond_lists"], "cpu")
+    assert rows.dtype == torch.uint8 and tuple(rows.shape) == (5000, 80)
+    assert np.array_equal(rows.numpy(), encode_rows(ident, b["segment_lists"], b["bond_lists"]))
+    # fresh list objects per row (no shared identity): still one table entry per distinct structure is not required, only equal rows
+    segs = [[list(a), list(c)] for a, c in b["segment_lists"][:200]]
+    bonds = [[[list(p) for p in a], [list(p) for p in c]] for a, c in b["bond_lists"][:200]]
+    assert np.array_equal(encode_rows_device(ident, segs, bonds, "cpu").numpy(), encode_rows(ident, segs, bonds))
+    assert tuple(encode_rows_device(ident, [], [], "cpu").shape) == (0, 80)
