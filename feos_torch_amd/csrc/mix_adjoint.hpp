@@ -166,7 +166,7 @@ PCS_DEV void adjoint_core(const C& c, double q0, double q1, double b0, double b1
             phi3d = phi3d + rrr[t] * Pd;
         }
         R f2(1.0), f3(0.0);  // da/dphi2, da/dphi3 (phi2 = phi3 = 0: a = phi2, see core_terms)
-        if (re(phi2) != 0.0) {
+        if (!(fabs(re(phi2)) < 1e-90)) {  // (trace polar component: the limit a = phi2, as core_terms)
             const R rd = d_recip(phi2 - phi3), rd2 = rd * rd;
             f2 = (phi2 * (phi2 - 2.0 * phi3)) * rd2;
             f3 = (phi2 * phi2) * rd2;

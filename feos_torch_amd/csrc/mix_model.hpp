@@ -322,8 +322,11 @@ PCS_DEV R core_terms_z(const C& c, const R& r0, const R& r1, const Z& zeta3, Pac
         R phi3 = (r00 * r0) * horner_z<4>(c.tj[0], zeta3) + (r00 * r1) * horner_z<4>(c.tj[1], zeta3) +
                  (r0 * r11) * horner_z<4>(c.tj[2], zeta3) + (r11 * r1) * horner_z<4>(c.tj[3], zeta3);
         // phi2 = phi3 = 0 where no polar component is present (pure-component limit next to a polar partner): the
-        // quotient's limit is phi2 + O(rho_polar^3) (value and gradient 0, Hessian that of phi2)
-        if (re(phi2) == 0.0) a = a + phi2;
+        // quotient's limit is phi2 + O(rho_polar^3) (value and gradient 0, Hessian that of phi2).  The same limit for a TRACE
+        // polar component (|phi2| < 1e-90: partial densities below ~1e-45 of the liquid's): the quotient's second
+        // derivatives carry 1/phi2^3, which overflows fp64 there and turned the Newton steps of dew rows whose incipient
+        // liquid holds ~1e-50 of the polar component into NaN; the neglected phi3 term is O(rho_polar^3) < 1e-135
+        if (fabs(re(phi2)) < 1e-90) a = a + phi2;
         else a = a + (phi2 * phi2) * d_recip(phi2 - phi3);
     }
     return a;

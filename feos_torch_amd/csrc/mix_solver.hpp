@@ -101,6 +101,11 @@ PCS_DEV bool solve3(double A[3][4], double* x) {
 // workload; rows that need more are reported as failed (status 1), as are successive-substitution
 // runs that have not settled after SS_MAX_IT sweeps.  The CPU oracle uses the same caps.
 constexpr int SS_MAX_IT = 40;
+// ... and, for a trace component, no longer in relative ones: |d ln(x_1/x_2)| of the sweep below SS_RES_TOL (with x_2 ~ 1e-6
+// falling by the damped factor 5 per sweep the absolute change of x_1 is below SS_TOL long before the trace component has
+// found its level; the Newton then starts in the dimerisation regime of a strongly associating trace component, where
+// d mu / d ln rho changes sign, and runs away)
+constexpr double SS_RES_TOL = 1e-2;
 constexpr double SS_TOL = 1e-5;        // composition change at which the dew-point successive substitution hands over to Newton
 // A Newton iteration whose largest step has not shrunk by NEWTON_PROGRESS (relative to the smallest one so far) within
 // NEWTON_NO_PROGRESS iterations is given up: it cycles (typically a 2-cycle whose amplitude creeps down by 1e-3 per
@@ -110,6 +115,11 @@ constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;
 constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double NEWTON_TRACE = 1e-4, NEWTON_TRACE_MAX = 100.0;  // see the Newton step below
 constexpr int NEWTON_MAX_IT = 60;
+// An iteration whose step has stopped shrinking below NEWTON_FLOOR (ratio >= 0.25) sits on the rounding floor of its residuals
+// (a trace component: the liquid's chemical potential of a component at x ~ 1e-13 carries ~1e-7 of noise) and is accepted;
+// the reference's final formula is second order in the remaining step (<= 1e-12).  1e-7 until round 3: rows cycling at
+// 4e-7 ... 9e-7 ran into the no-progress exit and failed.
+constexpr double NEWTON_FLOOR = 1e-6;
 
 struct MixResult {
     double spec0, spec1, inc0, inc1;  // converged partial densities

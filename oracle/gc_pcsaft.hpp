@@ -219,7 +219,8 @@ S gc_helmholtz_energy_density(const GcRow& r, const S& T, const S* rho, const S*
         phi2 = phi2 * PI;
         phi3 = phi3 * (4.0 / 3.0 * PI * PI);
         // 0/0 where no polar component is present: limit phi2 + O(rho_polar^3) (see pcsaft_mix.hpp)
-        if (re(phi2) == 0.0) phi = phi + phi2;
+        // also for a trace polar component (|phi2| < 1e-90): 1/phi2^3 in the second derivatives overflows fp64 (pcsaft_mix.hpp)
+        if (fabsl((long double)re(phi2)) < 1e-90L) phi = phi + phi2;
         else phi = phi + phi2 * phi2 / (phi2 - phi3);
     }
 

@@ -71,10 +71,11 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
 // the scaled function is nearly linear).  Only used to initialise the phase-equilibrium Newton, so
 // a relative step of LIQ_ROOT_TOL suffices.  Same logic and caps as csrc/mix_solver.hpp.
 constexpr double LIQ_ROOT_TOL = 1e-3;  // as csrc/mix_solver.hpp
-constexpr double STAB_REJECT = -0.5;   // as csrc/mix_solver_sm.hpp: det(M) <= STAB_REJECT |M00 M11| -> unstable liquid
 constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
 constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double NEWTON_TRACE = 1e-4, NEWTON_TRACE_MAX = 100.0;
+constexpr double SS_RES_TOL = 1e-2;     // as csrc/mix_solver.hpp
+constexpr double NEWTON_FLOOR = 1e-6;  // as csrc/mix_solver.hpp: a step that has stopped shrinking below it sits on the rounding floor and is accepted
 constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point successive substitution hands over to Newton
 // Robust form of the liquid root (second pass of the solvers, csrc/mix_solver.hpp: ROBUST): a bracket [lo, hi] with
 // p(lo) < p_spec < p(hi), dp(hi) > 0 is established first -- hi = the first of eta = 0.5, 0.62, 0.70, 0.78, 0.86 at which p
@@ -213,15 +214,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         }
         F r[2] = {z[0] * rs, z[1] * rs};
         PhaseEval<F> e = eval_phase<F>(model, T, r);
-        if (robust) {
-            // the specified liquid must be diffusionally stable (as csrc/mix_solver_sm.hpp): 98 % of the rows that fail are
-            // liquids inside a liquid-liquid spinodal, for which the bubble curve has no branch through this composition
-            F m00 = F(1) / r[0] + e.h[0][0], m11 = F(1) / r[1] + e.h[1][1];
-            static const double thr = getenv("ORC_STAB_THRESH") ? atof(getenv("ORC_STAB_THRESH")) : STAB_REJECT;
-            F am = m00 * m11;
-            if (am < 0) am = -am;
-            if (!(m00 * m11 - e.h[0][1] * e.h[0][1] > F(thr) * am)) return false;
-        }
+        // (no stability test of the specified liquid any more: as csrc/mix_solver_sm.hpp, round 3)
         for (int i = 0; i < 2; i++) ri[i] = r[i] * exp(e.g[i]);
     } else {
         // Raoult: zero-pressure pure-liquid fugacities f_i, p = 1/sum(y_i/f_i), x_i = y_i p/f_i
@@ -362,7 +355,11 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             }
             p0 = F(1) / sum;
             if (getenv("ORC_TRACE")) fprintf(stderr, "ss %d x %.6e %.6e p0 %.6e rl %.6e dx %.3e\n", ss, (double)x[0], (double)x[1], (double)p0, (double)rl, (double)dx);
-            if (dx < F(ss_tol) || narrow) break;
+            // settled: the composition no longer moves -- in absolute terms AND, for a trace component, in relative ones
+            // (|res| = |d ln(x_1/x_2)| of the sweep; with x_2 ~ 1e-6 falling by the damped factor 5 per sweep the absolute
+            // change of x_1 drops below the tolerance long before the trace component has found its level)
+            F ares = res < 0 ? -res : res;
+            if ((dx < F(ss_tol) && ares < F(SS_RES_TOL)) || narrow) break;
         }
         if (!have) return false;
         if (!ss_track && !liquid_root<F>(model, T, x, p0, rl, F(0), robust) && !liquid_root<F>(model, T, x, F(0), rl, F(0), robust)) return false;
@@ -420,7 +417,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             F dtot = ri[0] + ri[1] - rs, d0 = ri[0] - z[0] * rs;
             if ((dtot < 0 ? -dtot : dtot) <= F(1e-6) * rs && (d0 < 0 ? -d0 : d0) <= F(1e-6) * rs) return false;
         }
-        bool stagnated = it >= 3 && mx < F(1e-7) && mx >= F(0.25) * err_prev;
+        bool stagnated = it >= 3 && mx < F(NEWTON_FLOOR) && mx >= F(0.25) * err_prev;
         err_prev = mx;
         if (mx <= tol || stagnated) {
             F dens_s = rs, dens_i = ri[0] + ri[1];

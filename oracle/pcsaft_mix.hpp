@@ -124,7 +124,10 @@ S phi_dipole(const MixParams<S>& q, const S& T, const S* rho, const S* etas) {
     // phi2 and phi3 vanish together where no polar component is present (a pure-component limit of a
     // mixture with one polar partner): the quotient is 0/0 in the reference's Python; its limit is
     // phi2 + O(rho_polar^3), which is what feos' dipole term (the solver's own model) returns there.
-    if (re(phi2) == 0.0) return phi2;
+    // ... and the same limit is taken for a TRACE polar component (|phi2| < 1e-90, i.e. partial densities below ~1e-45 of the
+    // liquid's): the second derivatives of the quotient carry 1/phi2^3, which overflows fp64 there (NaN Newton steps on dew
+    // rows whose incipient liquid holds 1e-50 of the polar component); the neglected phi3 term is O(rho_polar^3) < 1e-135
+    if (fabsl((long double)re(phi2)) < 1e-90L) return phi2;
     return phi2 * phi2 / (phi2 - phi3);
 }
 

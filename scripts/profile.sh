@@ -6,7 +6,7 @@
 # collected in their own runs (never combined with tracing other than kernel-trace); the VALU issue costs the summary
 # weighs the instruction classes with come from scripts/microbench/issue_cost.hip, run here as well.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT
