@@ -47,6 +47,7 @@ SIGNATURES = {
     "pcs_mix_derivatives_vjp": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_gc_derivatives_vjp": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_mixn_derivatives": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "pcs_mixn_derivatives_vjp": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_mix_derivatives": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 

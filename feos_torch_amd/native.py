@@ -675,3 +675,22 @@ def mixn_derivatives(params, temperature, density):
                                     _lib.ptr(mu), _lib.ptr(v), _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_mixn_derivatives")
     return a, p, mu, v
+
+
+def mixn_derivatives_vjp(params, temperature, density, g_a=None, g_p=None, g_mu=None, g_v=None):
+    """Backward of the n-component derivatives: grad [n, 9 nc + 1] = dL/d(parameters [nc][8], T, rho [nc])."""
+    device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
+    nc = int(params.shape[1])
+    params = _prep(params, device, (nc, 8))
+    temperature = _prep(temperature, device)
+    density = _prep(density, device, (nc,))
+    g_a, g_p, g_mu, g_v = _opt(g_a, device), _opt(g_p, device), _opt(g_mu, device, (nc,)), _opt(g_v, device, (nc,))
+    n = temperature.shape[0]
+    _same_rows(n, parameters=params, density=density, g_a=g_a, g_p=g_p, g_mu=g_mu, g_v=g_v)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        grad = torch.empty((n, 9 * nc + 1), dtype=_F64, device=device)
+        rc = L.pcs_mixn_derivatives_vjp(_lib.ptr(params), _lib.ptr(temperature), _lib.ptr(density), nc, n, _lib.ptr(g_a), _lib.ptr(g_p),
+                                        _lib.ptr(g_mu), _lib.ptr(g_v), _lib.ptr(grad), _lib.current_stream_ptr(device))
+        _lib.check(rc, "pcs_mixn_derivatives_vjp")
+    return grad

@@ -90,6 +90,36 @@ class _MixDerivatives(torch.autograd.Function):
                 g[:, 18].contiguous().to(d[2]) if need[2] else None, g[:, 19:21].contiguous().to(d[3]) if need[3] else None)
 
 
+class _MixnDerivatives(torch.autograd.Function):
+    """n-component (a, p, mu, v) with gradients to parameters [n,nc,8], temperature and density [n,nc] (the reference's model is
+    a torch graph for any number of components, feos_torch/pcsaft_mix.py:31-154, :395-420)."""
+
+    @staticmethod
+    def forward(ctx, parameters, temperature, density):
+        dev = native._dev() if not parameters.is_cuda else parameters.device
+        nc = int(parameters.shape[1])
+        par = native._prep(parameters, dev, (nc, 8))
+        T = native._prep(temperature, dev)
+        rho = native._prep(density, dev, (nc,))
+        a, p, mu, v = native.mixn_derivatives(par, T, rho)
+        ctx.save_for_backward(par, T, rho)
+        ctx.set_materialize_grads(False)
+        ctx.in_devices = (parameters.device, temperature.device, density.device)
+        out = parameters.device
+        return a.to(out), p.to(out), mu.to(out), v.to(out)
+
+    @staticmethod
+    def backward(ctx, g_a, g_p, g_mu, g_v):
+        par, T, rho = ctx.saved_tensors
+        if g_a is None and g_p is None and g_mu is None and g_v is None:
+            return None, None, None
+        n, nc = rho.shape
+        g = native.mixn_derivatives_vjp(par, T, rho, g_a, g_p, g_mu, g_v)
+        need, d = ctx.needs_input_grad, ctx.in_devices
+        return (g[:, : 8 * nc].reshape(n, nc, 8).to(d[0]) if need[0] else None, g[:, 8 * nc].contiguous().to(d[1]) if need[1] else None,
+                g[:, 8 * nc + 1:].contiguous().to(d[2]) if need[2] else None)
+
+
 class PcSaftMix:
     def __init__(self, parameters, kij=None):
         """parameters: [N, 2, 8] float64 (component rows as for PcSaftPure); kij: [N, 2] with
@@ -107,8 +137,6 @@ class PcSaftMix:
                 raise ValueError("between 1 and 6 components are supported")
             if bool((((parameters[:, :, 6] + parameters[:, :, 7]) != 0).sum(dim=1) > 1).any()):
                 raise Exception("Only up to two associating components are allowed, and two only for binary mixtures!")
-            if parameters.requires_grad:
-                raise NotImplementedError("gradients of the n-component state functions are not provided (binary mixtures are)")
         elif kij is None:
             kij = torch.zeros((parameters.shape[0], 2), dtype=parameters.dtype, device=parameters.device)
         self._set(parameters, kij)
@@ -144,16 +172,12 @@ class PcSaftMix:
         return self.derivatives(temperature, density)[0][:, None]
 
     def derivatives(self, temperature, density):
-        """(a [N], p [N], mu [N,2], v [N,2]) (:395-420); differentiable w.r.t. parameters, kij, temperature and density
-        (pcs_mix_derivatives_vjp is the backward pass)."""
+        """(a [N], p [N], mu [N,n], v [N,n]) (:395-420); differentiable w.r.t. parameters, kij, temperature and density
+        (pcs_mix_derivatives_vjp / pcs_mixn_derivatives_vjp are the backward passes)."""
         temperature = torch.as_tensor(temperature, dtype=torch.float64)
         density = torch.as_tensor(density, dtype=torch.float64)
         if self.ncomp != 2:
-            if temperature.requires_grad or density.requires_grad:
-                raise NotImplementedError("the n-component state functions are forward only (binary mixtures are differentiable)")
-            a, p, mu, v = native.mixn_derivatives(self._par, temperature, density)
-            dev = self._par.device
-            return a.to(dev), p.to(dev), mu.to(dev), v.to(dev)
+            return _MixnDerivatives.apply(self._par, temperature, density)
         return _MixDerivatives.apply(self._par, self.kij, temperature, density)
 
     def _bubble_dew(self, dew, temperature, molefracs, pressure):

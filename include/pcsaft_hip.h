@@ -166,6 +166,16 @@ int pcs_mixn_derivatives(const double* params, const double* temp, const double*
                          double* mu, double* v, void* stream);
 
 /*
+ * Backward pass of pcs_mixn_derivatives -- the reference's n-component model is an ordinary torch graph
+ * (feos_torch/pcsaft_mix.py:31-154, :395-420), so its autograd reaches parameters, temperature and densities:
+ *   grad [n, 9 ncomp + 1] = d L / d (params [ncomp][8], T, rho [ncomp]),  L = g_a a + g_p p + g_mu . mu + g_v . v
+ * with the upstream gradients g_a [n], g_p [n], g_mu [n,ncomp], g_v [n,ncomp] (each optional, NULL = 0).  One forward-mode
+ * pass per input direction through the same model code (correct first, not tuned: 9 ncomp + 1 evaluations per row).
+ */
+int pcs_mixn_derivatives_vjp(const double* params, const double* temp, const double* rho, int ncomp, int64_t n, const double* g_a,
+                             const double* g_p, const double* g_mu, const double* g_v, double* grad, void* stream);
+
+/*
  * Gradient of the bubble (dew = 0) / dew (dew = 1) pressure [Pa] at the converged densities rho4
  * (from pcs_mix_bubble_dew) — what torch reverse mode through feos_torch/pcsaft_mix.py:435-444 /
  * :459-468 yields.  jac [n,19] = d p / d (params[0,0..7], params[1,0..7], kij[0], kij[1], T).

@@ -125,3 +125,86 @@ def test_api_errors(amd):
         eos.derivatives(_t(T[:3]), _t(rho))
     with pytest.raises(ValueError):
         amd.PcSaftMix(_t(np.zeros((2, 7, 8))))
+
+
+def test_vjp_nc2_equals_the_binary_backward(amd):
+    """n = 2, k_ij = 0, at most one associating component: the n-component backward pass (pcs_mixn_derivatives_vjp) against the
+    binary one (pcs_mix_derivatives_vjp), which tests/test_deriv_grad_gpu.py pins on the reference's own autograd."""
+    from feos_torch_amd import native
+
+    P, T, rho = random_rows(400, 2, seed=31)
+    n = len(T)
+    rng = np.random.default_rng(2)
+    ga, gp, gmu, gv = rng.normal(size=n), rng.normal(size=n), rng.normal(size=(n, 2)), rng.normal(size=(n, 2)) * 1e-3
+    d = lambda x: _t(x).cuda()
+    g = native.mixn_derivatives_vjp(d(P), d(T), d(rho), d(ga), d(gp), d(gmu), d(gv)).cpu().numpy()
+    gb = native.mix_derivatives_vjp(d(P), d(np.zeros((n, 2))), d(T), d(rho), d(ga), d(gp), d(gmu), d(gv)).cpu().numpy()
+    want = np.concatenate([gb[:, 0:16], gb[:, 18:21]], axis=1)  # (16 parameters, T, rho_0, rho_1); k_ij columns dropped
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    assert np.max(np.abs(g - want) / scale) < 1e-9
+
+
+@pytest.mark.parametrize("nc", [1, 3, 4, 6])
+def test_vjp_vs_finite_differences_of_the_oracle(amd, oracle, nc):
+    """dL/d(parameters, T, rho) for nc components against central differences of L evaluated with the long-double oracle
+    restatement (oracle/pcsaft_mixn.hpp)."""
+    from feos_torch_amd import native
+
+    P, T, rho = random_rows(24, nc, seed=40 + nc)
+    n = len(T)
+    rng = np.random.default_rng(nc)
+    ga, gp, gmu, gv = rng.normal(size=n), rng.normal(size=n), rng.normal(size=(n, nc)), rng.normal(size=(n, nc)) * 1e-3
+    d = lambda x: _t(x).cuda()
+    g = native.mixn_derivatives_vjp(d(P), d(T), d(rho), d(ga), d(gp), d(gmu), d(gv)).cpu().numpy()
+
+    def L(P_, T_, rho_):
+        a, p, mu, v = oracle.mixn_derivatives(P_, T_, rho_, prec=1)
+        return ga * a + gp * p + (gmu * mu).sum(axis=1) + (gv * v).sum(axis=1)
+
+    fd = np.zeros_like(g)
+    for k in range(8 * nc + 1 + nc):
+        Pp, Pm, Tp, Tm, rp, rm = P.copy(), P.copy(), T.copy(), T.copy(), rho.copy(), rho.copy()
+        if k < 8 * nc:
+            c, q = divmod(k, 8)
+            if q >= 6 or np.all(P[:, c, q] == 0.0):
+                # site counts (class switches) and columns that are zero on every row (the relative step has nothing to scale
+                # with; the reference's formula still has a derivative there, e.g. w.r.t. kappa_ab of a site-less component,
+                # :211-218): not compared
+                fd[:, k] = g[:, k]
+                continue
+            h = 1e-6 * np.where(P[:, c, q] != 0.0, np.abs(P[:, c, q]), 1.0)
+            Pp[:, c, q] += h
+            Pm[:, c, q] -= h
+            mask = P[:, c, q] != 0.0
+        elif k == 8 * nc:
+            h = 1e-6 * T
+            Tp, Tm = T + h, T - h
+            mask = np.ones(n, bool)
+        else:
+            i = k - 8 * nc - 1
+            h = 1e-6 * rho[:, i]
+            rp[:, i] += h
+            rm[:, i] -= h
+            mask = np.ones(n, bool)
+        fd[:, k] = np.where(mask, (L(Pp, Tp, rp) - L(Pm, Tm, rm)) / (2 * h), g[:, k])
+    cols = [k for k in range(9 * nc + 1) if not (k < 8 * nc and k % 8 >= 6)]
+    scale = np.abs(fd[:, cols]).max(axis=1, keepdims=True) + 1e-300
+    err = np.abs(g[:, cols] - fd[:, cols]) / np.maximum(np.abs(fd[:, cols]), 1e-6 * scale)
+    assert np.nanmax(err) < 2e-4, np.nanmax(err)
+
+
+def test_shell_is_differentiable_for_three_components(amd):
+    from feos_torch_amd import PcSaftMix
+
+    P, T, rho = random_rows(50, 3, seed=77)
+    Pt = _t(P).cuda().requires_grad_(True)
+    Tt = _t(T).cuda().requires_grad_(True)
+    rt = _t(rho).cuda().requires_grad_(True)
+    a, p, mu, v = PcSaftMix(Pt).derivatives(Tt, rt)
+    (a.sum() + p.sum() + mu.sum()).backward()
+    assert Pt.grad.shape == (50, 3, 8) and torch.isfinite(Pt.grad).all() and torch.isfinite(Tt.grad).all() and torch.isfinite(rt.grad).all()
+    # d a / d rho_i = mu_i (the residual chemical potential is the density derivative of the Helmholtz energy density)
+    Pt2, rt2 = _t(P).cuda(), _t(rho).cuda().requires_grad_(True)
+    a2, _, mu2, _ = PcSaftMix(Pt2).derivatives(_t(T).cuda(), rt2)
+    a2.sum().backward()
+    assert torch.allclose(rt2.grad, mu2.detach(), rtol=1e-10, atol=1e-12)
