@@ -132,7 +132,7 @@ PCS_DEV void adjoint_axpy(const PureCoef<double>& c, PureCoefAdj<double>& adj, c
 
 // WHICH: 0 vapor_pressure [Pa], 1 liquid_density [kmol/m3], 2 equilibrium_liquid_density [kmol/m3]
 template <int WHICH>
-PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv, double rl, double g[JAC_DIRS]) {
+PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv, double rl, double g[JAC_DIRS], bool polish = false) {
     typedef DN<double, JAC_CHUNK> G;
     constexpr int NPASS = (JAC_DIRS + JAC_CHUNK - 1) / JAC_CHUNK;
     {
@@ -143,6 +143,17 @@ PCS_DEV void pure_jacobian(const double par[8], double T, double p_pa, double rv
         // the coefficients appear, so the 33 x 9 tangents never sit in registers together.
         PureCoef<double> c0;
         pure_coef<double>(c0, par, T, true);
+        if (WHICH == 0 && polish) {
+            // densities from the pressure-only kernel (pcs_pure_vapor_pressure: ~1e-9 from the root on ordinary rows, 1e-5 close
+            // to the critical point where dp/drho -> 0): one fp64 Newton step of the coupled iteration (vle_step, quadratic)
+            // before the derivatives are taken; the pressure itself is not touched
+            const Eval l = pure_eval(c0, rl), v = pure_eval(c0, rv);
+            const VleStep s = vle_step(l, v, rl, rv);
+            if (is_finite_bits(s.dl) && is_finite_bits(s.dv) && fabs(s.dl) < 0.1 * rl && fabs(s.dv) < 0.5 * rv) {
+                rl += s.dl;
+                rv += s.dv;
+            }
+        }
         PureCoefAdj<double> adj;
         adj.m = adj.mm1 = adj.ceta = adj.kd1 = adj.kd2 = adj.qm = adj.da = adj.na = adj.nb = 0.0;
 #pragma unroll

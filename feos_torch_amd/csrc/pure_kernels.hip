@@ -339,22 +339,9 @@ __global__ __launch_bounds__(BLOCK, K4_WAVES) void k_pure_jacobian(const double*
     const int64_t ii = live ? i : n - 1;
     const double T = temp[ii];
     const double p_pa = (WHICH == 1) ? pressure[ii] : 0.0;
-    double rv = rho_vl[2 * ii], rl = rho_vl[2 * ii + 1];
-    if (WHICH == 0 && polish) {
-        // densities from the pressure-only kernel (pcs_pure_vapor_pressure: ~1e-9 from the root on ordinary rows, 1e-5 close
-        // to the critical point where dp/drho -> 0): one fp64 Newton step of the coupled iteration (vle_step, quadratic) before
-        // the derivatives are taken; the pressure itself is not touched
-        PureCoef<double> cp;
-        pure_coef<double>(cp, par, T, false);
-        const Eval l = pure_eval(cp, rl), v = pure_eval(cp, rv);
-        const VleStep s = vle_step(l, v, rl, rv);
-        if (is_finite_bits(s.dl) && is_finite_bits(s.dv) && fabs(s.dl) < 0.1 * rl && fabs(s.dv) < 0.5 * rv) {
-            rl += s.dl;
-            rv += s.dv;
-        }
-    }
+    const double rv = rho_vl[2 * ii], rl = rho_vl[2 * ii + 1];
     double g[10];
-    pure_jacobian<WHICH>(par, T, p_pa, rv, rl, g);
+    pure_jacobian<WHICH>(par, T, p_pa, rv, rl, g, polish != 0);
     if (!live) return;
     // a failed row carries zero densities -> NaNs; the caller masks by status
     if (jac) {
