@@ -52,8 +52,17 @@ def test_failed_rows_have_no_reachable_solution(oracle, dew):
     print(f"   sample of {len(ok)} solved rows: continuation solves {both.sum()}, same solution on {same.sum()}, another solution on {(~same).sum()}, "
           f"max rel among the same {rel[same].max():.2e}")
     assert both.mean() > 0.9
-    assert same.mean() > (0.93 if dew else 0.99)
+    assert same.mean() > (0.95 if dew else 0.99)
     assert rel[same].max() < 1e-8
+    # ... and where the two solvers land on DIFFERENT solutions, the kernel's is the stable one: at fixed vapour composition
+    # the dew point is the LOWEST pressure at which a liquid can form (above it the vapour would already have condensed), at
+    # fixed liquid composition the bubble point is the HIGHEST pressure at which a vapour can form.  Round 3, 12,000 rows on
+    # the CPU restatement: 191 of 198 differing dew rows and 19 of 21 differing bubble rows on the stable side -- the
+    # continuation solver, which follows one branch from a pure-component end, is the one that lands on the metastable root.
+    stable_side = (got[both] < pC[both]) if dew else (got[both] > pC[both])
+    ok_root = same | stable_side
+    print(f"   of the {(~same).sum()} rows with another solution the kernel's is the stable one on {(~same & stable_side).sum()}")
+    assert ok_root.mean() >= 0.995
 
 
 def test_two_schedules_agree_including_the_second_pass():
