@@ -5,7 +5,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpcsaft_hip.so")
-SOURCES = ["pure_kernels.hip", "pure_robust.hip", "compact_kernels.hip", "mix_kernels.hip", "mixn_kernels.hip", "gc_kernels.hip", "gc_gradient.hip"]
+# (source, object, extra flags).  pure_kernels.hip is compiled twice: part 1 with re-association (pressure-only VLE kernel,
+# Jacobians, C ABI), part 2 without (all-fp64 VLE kernel, liquid density): see the head of the file
+SOURCES = [("pure_kernels.hip", "pure_kernels.o", ["-DPCS_PURE_PART=1"]), ("pure_kernels.hip", "pure_kernels_b.o", ["-DPCS_PURE_PART=2"]),
+           ("pure_robust.hip", "pure_robust.o", []), ("compact_kernels.hip", "compact_kernels.o", []),
+           ("mix_kernels.hip", "mix_kernels.o", []), ("mixn_kernels.hip", "mixn_kernels.o", []),
+           ("gc_kernels.hip", "gc_kernels.o", []), ("gc_gradient.hip", "gc_gradient.o", [])]
 # -fno-honor-nans/-infinities/-signed-zeros: lets the compiler fold the structural zeros of the dual
 # numbers (0 * x, x + 0); every NaN/inf test in the kernels is a bit test (is_finite_bits), so the
 # failure detection does not depend on IEEE comparison semantics.  Measured on k_pure_vle: x1.065,
@@ -18,7 +23,14 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 # -fno-slp-vectorize: the SLP vectoriser pairs fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 and pays for it with
 # ~25 % v_mov (operand pairs must sit in adjacent registers) and 168 instead of 122 VGPRs on k_pure_vle<true> (3 instead of
 # 4 waves per SIMD): 1.184 -> 0.943 ms per 1e7 rows without it (scripts/dev/ab_bench.py, round 2).
-RELAXED = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros", "-fno-slp-vectorize", "-DPCS_FAST_RCP", "-DPCS_FAST_LOG", "-DPCS_F32_PRESOLVE"]
+# REASSOC = -fassociative-math -freciprocal-math (round 3): the compiler may re-associate sums / products and turn x / y into
+# x * (1 / y): k_pure_vle<true> 0.783 -> 0.750 ms per 1e7 rows (x1.044, scripts/dev/ab_bench.py; -ffast-math as a whole gives
+# the same), Jacobian kernels x1.13; the all-fp64 VLE kernel and the liquid-density kernel get SLOWER with it (x0.96, x0.75),
+# hence the two parts.  The explicit fma chains of the logarithm / reciprocal refinements are untouched, and the parity of
+# the kernels against the long-double oracle is unchanged (tests/test_large_parity_gpu.py: 1e-10 on 1e6 rows).
+RELAXED = ["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros", "-fno-slp-vectorize", "-DPCS_FAST_RCP", "-DPCS_FAST_LOG",
+           "-DPCS_F32_PRESOLVE"]
+REASSOC = ["-fassociative-math", "-freciprocal-math"]  # part 1 of pure_kernels.hip only
 RELAXED_SOURCES = {"pure_kernels.hip"}
 # mixture / gc solver units: the short logarithm and the refined hardware reciprocal in their guarded forms (=2: IEEE
 # results for zero, infinite, NaN and negative arguments, which the solvers' failure detection relies on; dual.hpp).
@@ -71,9 +83,10 @@ def build(force=False, verbose=False):
     # one hipcc per translation unit in parallel, then link
     objs, procs = [], []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    for s in SOURCES:
-        obj = os.path.join(HERE, "build", s.replace(".hip", ".o"))
-        cmd = ["hipcc"] + FLAGS + (RELAXED if s in RELAXED_SOURCES else []) + (GUARDED if s in GUARDED_SOURCES else []) + ["-c", "-o", obj, os.path.join(CSRC, s)]
+    for s, oname, extra in SOURCES:
+        obj = os.path.join(HERE, "build", oname)
+        cmd = (["hipcc"] + FLAGS + (RELAXED if s in RELAXED_SOURCES else []) + (REASSOC if "-DPCS_PURE_PART=1" in extra else [])
+               + (GUARDED if s in GUARDED_SOURCES else []) + extra + ["-c", "-o", obj, os.path.join(CSRC, s)])
         if verbose:
             print(" ".join(cmd))
         # the compiler's per-kernel register / stack report is kept next to the objects (tests/test_abi.py guards the

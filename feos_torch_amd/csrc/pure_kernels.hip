@@ -17,17 +17,36 @@
 #include "pure_solver.hpp"
 #include "pure_jacobian.hpp"
 
+// This file is compiled TWICE (feos_torch_amd/build.py), with the same relaxed floating-point flags but
+//   PCS_PURE_PART = 1  with -fassociative-math -freciprocal-math: the pressure-only VLE kernel (0.783 -> 0.750 ms per 1e7 rows,
+//                      x1.044), the Jacobian kernels (x1.13), fallback, derivatives, their VJP, and the whole C ABI;
+//   PCS_PURE_PART = 2  without: the all-fp64 VLE kernel and the liquid-density kernel, which re-association makes SLOWER
+//                      (x0.96; 0.895 -> 1.19 ms: the re-associated expressions cost k_pure_liquid_density its register budget),
+//                      behind two launch functions that part 1 calls.
+// Measured in one process with scripts/dev/ab_bench.py / ab_k2.py / ab_purejac.py (round 3).  A build-level switch like
+// PCS_FAST_RCP, not an experiment: both parts are always built and linked.
+#ifndef PCS_PURE_PART
+#define PCS_PURE_PART 1
+#endif
+
 // stage 2 (k_pure_vle_robust) lives in pure_robust.hip, compiled with strict IEEE semantics
 namespace pcs_abi {
 int launch_pure_vle_retry(const double* params, const double* temp, double* p_sat, double* rho_eq, double* rho_vl,
                           uint8_t* status, int32_t* iters, const int32_t* retry, int64_t n, hipStream_t s);
+// part 2 of this file
+int launch_pure_vle_full(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq, double* rho_vl,
+                         uint8_t* status, int32_t* iters, int32_t* retry, hipStream_t s);
+int launch_pure_liquid_density(const double* params, const double* temp, const double* pressure, int64_t n, double* rho_out,
+                               double* rho_root, uint8_t* status, hipStream_t s);
 }
 #define launch_vle_retry pcs_abi::launch_pure_vle_retry
 
 using namespace pcs;
 using namespace pcs_abi;
 
+#if PCS_PURE_PART == 1
 thread_local char pcs_abi::g_err[256] = "";
+#endif
 
 namespace {
 
@@ -170,6 +189,7 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
 
 // Rows of the list with bit 31 set (no usable fp32 pre-solve): the all-fp64 fast path.  Solved rows keep the
 // bit (the robust pass skips them), rows that need the robust pass get it cleared.
+#if PCS_PURE_PART == 1
 constexpr int FALLBACK_GRID = 1024;
 __global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restrict__ params, const double* __restrict__ temp,
                                                           double* __restrict__ p_sat, double* __restrict__ rho_eq,
@@ -210,8 +230,11 @@ __global__ __launch_bounds__(64) void k_pure_vle_fallback(const double* __restri
 // ------------------------------------------------------------------------------------------
 // liquid-density kernel: 204 VGPRs fit two waves per SIMD; held to 168 (52 spill instructions) three: 1.02 -> 0.89 ms per 1e7
 // rows (four, 128 VGPRs: 1.02 ms)
+#endif  // part 1
+
 constexpr int K4_WAVES = 2;  // Jacobian kernels: two (256 VGPRs); held to 168 for three they spill inside the DN<9> pass: 0.89 -> 2.24 ms
 constexpr int K2_WAVES = 3;
+#if PCS_PURE_PART == 2
 __global__ __launch_bounds__(BLOCK, K2_WAVES) void k_pure_liquid_density(const double* __restrict__ params,
                                                                const double* __restrict__ temp,
                                                                const double* __restrict__ pressure, int64_t n,
@@ -266,7 +289,9 @@ __global__ __launch_bounds__(BLOCK, K2_WAVES) void k_pure_liquid_density(const d
     if (rho_root) rho_root[i] = ok ? rho : 0.0;
     status[i] = ok ? 0 : 1;
 }
+#endif  // part 2
 
+#if PCS_PURE_PART == 1
 // ------------------------------------------------------------------------------------------
 // derivatives (a, p, dp) at given (T, rho)
 // ------------------------------------------------------------------------------------------
@@ -388,8 +413,34 @@ __global__ __launch_bounds__(BLOCK) void k_pure_derivatives_vjp(const double* __
     if (grad_rho) grad_rho[i] = g[9];
 }
 
+#endif  // part 1
+
 }  // namespace
 
+#if PCS_PURE_PART == 2
+// launch functions of the kernels compiled without re-association (called from part 1)
+namespace pcs_abi {
+int launch_pure_vle_full(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq, double* rho_vl,
+                         uint8_t* status, int32_t* iters, int32_t* retry, hipStream_t s) {
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_pure_vle<false>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status, iters,
+                       retry);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_vle launch", e);
+    return 0;
+}
+int launch_pure_liquid_density(const double* params, const double* temp, const double* pressure, int64_t n, double* rho_out,
+                               double* rho_root, uint8_t* status, hipStream_t s) {
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_pure_liquid_density, dim3(grid), dim3(BLOCK), 0, s, params, temp, pressure, n, rho_out, rho_root, status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("k_pure_liquid_density launch", e);
+    return 0;
+}
+}  // namespace pcs_abi
+#endif
+
+#if PCS_PURE_PART == 1
 extern "C" {
 
 int pcs_abi_version(void) { return 103; }  // 103: pcs_pure_vapor_pressure, pcs_compact_* / pcs_expand_rows
@@ -412,23 +463,22 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
     // second order in them), while rho_eq and the Jacobian kernels (rho_vl) want the ~1e-12 of the D2 finish.
     // (pcs_pure_vapor_pressure forces LITE and hands out those ~1e-9 densities: the property then has the same bits
     // whether or not its caller also wants the Jacobian.)
-    if (!rho_eq && (!rho_vl || force_lite))
+    if (!rho_eq && (!rho_vl || force_lite)) {
         hipLaunchKernelGGL(k_pure_vle<true>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                            iters, retry);
-    else
-        hipLaunchKernelGGL(k_pure_vle<false>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
-                           iters, retry);
+    } else if (int ef = launch_pure_vle_full(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, s)) {
+        return ef;
+    }
     hipLaunchKernelGGL(k_pure_vle_fallback, dim3(FALLBACK_GRID), dim3(64), 0, s, params, temp, p_sat, rho_eq, rho_vl, status,
                        iters, retry, n);
     e = hipGetLastError();
     if (e != hipSuccess) return fail("k_pure_vle launch", e);
     return 0;
+#else
+    (void)force_lite;
+    (void)e;
+    return launch_pure_vle_full(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, s);
 #endif
-    hipLaunchKernelGGL(k_pure_vle<false>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
-                       iters, retry);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail("k_pure_vle launch", e);
-    return 0;
 }
 
 static int vle_args_ok(const double* params, const double* temp, int64_t n, const uint8_t* status,
@@ -482,12 +532,7 @@ int pcs_pure_liquid_density(const double* params, const double* temp, const doub
     if (int e = check_n(n)) return e;
     if (n == 0) return 0;
     if (!params || !temp || !pressure || !status) return fail_msg("pcs_pure_liquid_density: null required pointer");
-    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_pure_liquid_density, dim3(grid), dim3(BLOCK), 0, as_stream(stream), params, temp, pressure,
-                       n, rho_out, rho_root, status);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail("k_pure_liquid_density launch", e);
-    return 0;
+    return launch_pure_liquid_density(params, temp, pressure, n, rho_out, rho_root, status, as_stream(stream));
 }
 
 int pcs_pure_derivatives(const double* params, const double* temp, const double* rho, int64_t n, double* a,
@@ -567,3 +612,4 @@ int pcs_pure_jacobian_vjp(int which, const double* params, const double* temp, c
 }
 
 }  // extern "C"
+#endif  // part 1
