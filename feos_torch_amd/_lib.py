@@ -30,6 +30,7 @@ SIGNATURES = {
     "pcs_compact_rows": (_int, [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp]),
     "pcs_expand_rows": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "pcs_pure_vle_fast": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcs_pure_vle_fp64": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_pure_vle_retry": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcs_pure_liquid_density": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pcs_pure_derivatives": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),

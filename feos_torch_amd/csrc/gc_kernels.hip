@@ -135,7 +135,12 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
         const double p_red = p_init[i] / (T * P_UNIT);
         const bool fast = !RETRY && retry;
         bool root_failed = false;
-        int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT, false, &root_failed);
+        // dew: the pure-liquid fugacities of Raoult's law on the one-variable evaluation (5 of a row's ~20 two-variable
+        // evaluations otherwise; round 3: dew 4.25 -> 4.02 ms per 1e6 rows)
+        double fug[2], rho_pure[2];
+        if (DEW) pure_fugacities_on_the_line(m, fug, rho_pure);
+        int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT, false, &root_failed,
+                                          DEW ? fug : nullptr, DEW ? rho_pure : nullptr);
         // a row that fails at a liquid root with the full caps gets the robust second attempt (bracketed liquid roots,
         // mix_solver_sm.hpp): in the second pass, or in place when there is no work list
         if (!fast && rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);

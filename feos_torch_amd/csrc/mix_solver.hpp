@@ -65,6 +65,14 @@ PCS_DEV PhaseEval phase_eval_inline(const Model& m, double r0, double r1) {
 template <class Model>
 PCS_EVAL_ATTR PhaseEval phase_eval(const Model& m, double r0, double r1) { return phase_eval_inline(m, r0, r1); }
 
+// a and its first two derivatives along the line rho_i = x_i rho (one-variable series: ~1/3 of the multiply-adds of the
+// two-variable evaluation above).  Not inlined either: the second evaluation site of the kernels that use it.
+template <class Model>
+PCS_EVAL_ATTR D2<double> line_eval(const Model& m, double x0, double x1, double rho) {
+    typedef D2<double> R;
+    return m.template a<R>(R(x0 * rho, x0, 0.0), R(x1 * rho, x1, 0.0));
+}
+
 // relative step at which a liquid root is accepted.  The roots only initialise the substitution / the Newton, and the
 // state machine carries the chemical potentials to the root to first order: 1e-3 leaves a 1e-6 error
 constexpr double LIQ_ROOT_TOL = 1e-3;

@@ -432,6 +432,59 @@ struct BdLane {
     }
 };
 
+// Zero-pressure liquid fugacities of the two PURE components for Raoult's law (dew points), found on the ONE-variable
+// evaluation along each component's axis before the state machine starts -- the same Newton iteration as the plain form's
+// S_ROOT stage (same start, scaled function, dense restart, acceptance rule and first-order carry of the chemical potential
+// to the root), so the state machine continues exactly where it would have been, to rounding.  All lanes of the wave run
+// it together (the roots need 2-4 evaluations whatever the row).  A root the plain form would give up on leaves NaN, and
+// the state machine takes its own route (robust second attempt).  fug[i] = rho_L,i exp(mu_res,i), rho[i] = rho_L,i.
+template <class Model>
+PCS_DEV void pure_fugacities_on_the_line(const Model& m, double fug[2], double rho_root[2]) {
+#pragma unroll 1
+    for (int comp = 0; comp < 2; comp++) {
+        const double x0 = comp == 0 ? 1.0 : 0.0, x1 = 1.0 - x0;
+        const double pk = m.packing(x0, x1);
+        double rho = 0.5 / pk, err_prev = 1.0, f = __longlong_as_double(0x7ff8000000000000LL), rr = 0.0;
+        bool dense = false, active = true;
+        int it = 0;
+        for (int guard = 0; guard < LIQ_ROOT_MAX_IT + 2; guard++) {
+            if (__ballot(active) == 0ull) break;
+            if (!active) continue;
+            const D2<double> a = line_eval(m, x0, x1, rho);
+            const double p = rho - a.v + rho * a.d1, dp = 1.0 + rho * a.d2;
+            if (it == 0 && !dense && !(p > 0.0)) {
+                rho = 0.62 / pk;
+                dense = true;
+                continue;
+            }
+            const double den = dense ? dp : dp - 4.0 * p * pk / (1.0 - rho * pk);
+            bool bad = !(dp > 0.0) || !(den > 0.0) || !is_finite_bits(p);
+            const double step = p / den, rho_new = rho - step;
+            bad = bad || !(rho_new > 0.0) || !is_finite_bits(rho_new);
+            bad = bad || (dense && !(rho_new * pk > 0.5 && rho_new * pk < 0.62));
+            bool done = false;
+            if (!bad) {
+                const double err = fabs(step) / rho;
+                done = err <= LIQ_ROOT_TOL || (it >= 3 && err < 1e-7 && err >= 0.25 * err_prev);
+                err_prev = err;
+                it++;
+                if (!done && it >= LIQ_ROOT_MAX_IT) bad = true;
+            }
+            if (bad) {
+                active = false;
+            } else if (done) {
+                f = rho_new * exp(a.d1 - a.d2 * step);
+                rr = rho_new;
+                active = false;
+            } else {
+                rho = rho_new;
+            }
+        }
+        fug[comp] = f;
+        rho_root[comp] = rr;
+    }
+}
+
 // Upper bound of the evaluations one row can need: 2 pure roots + (SS_MAX_IT sweeps each with a double root re-solve)
 // + 2 evaluations per Newton iteration.  Every driver of the state machine (single pass below, work queue in
 // mix_kernels.hip) gives a row up beyond it, so a stage transition that fails to advance a counter fails the row
@@ -442,9 +495,11 @@ constexpr int BD_EVAL_GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MA
 // Two attempts: the plain form, then -- only if one of its liquid roots failed -- the robust form (try_robust).
 template <bool DEW, class Model>
 PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
-                                int newton_max = NEWTON_MAX_IT, bool robust = false, bool* root_failed = nullptr) {
+                                int newton_max = NEWTON_MAX_IT, bool robust = false, bool* root_failed = nullptr,
+                                const double* fug = nullptr, const double* rho_pure = nullptr) {
     BdLane<DEW> L;
-    L.start(m, z0, p_init, ss_max, newton_max, robust);
+    if (fug) L.start(m, z0, p_init, ss_max, newton_max, robust, fug[0], fug[1], rho_pure[0], rho_pure[1]);
+    else L.start(m, z0, p_init, ss_max, newton_max, robust);
     for (int guard = 0; guard < (robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD); guard++) {
         if (__ballot(!L.done()) == 0ull) break;
         if (L.done()) continue;

@@ -106,7 +106,8 @@ __device__ __forceinline__ int k1_bucket(const double* row) {
 // tile whose callee-saved registers go through scratch (3.8 GB of HBM writes per 1e7 rows): not used.
 // LITE (pressure-only output, fp32 pre-solve available): vle_fast_lite; rows without a usable fp32 result are
 // appended with bit 31 set (k_pure_vle_fallback takes them), rows for the robust pass without.
-template <bool LITE>
+// POLISH (with LITE): the densities are handed out (rho_eq / rho_vl) and take the exact Newton update of vle_lite_finish<true>
+template <bool LITE, bool POLISH = false>
 __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure_vle(const double* __restrict__ params,
                                                     const double* __restrict__ temp, int64_t n,
                                                     double* __restrict__ p_sat, double* __restrict__ rho_eq,
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(BLOCK, LITE ? K1_WAVES_LITE : K1_WAVES) void k_pure
     VleResult res;
     int st;  // wave-uniform calls
 #ifdef PCS_F32_PRESOLVE
-    if (LITE) st = vle_fast_lite(&lds[r * ROW_PAD], lds[r * ROW_PAD + 8], res);  // the row is re-read from LDS for the fp64 coefficients
+    if (LITE) st = vle_fast_lite<POLISH>(&lds[r * ROW_PAD], lds[r * ROW_PAD + 8], res);  // the row is re-read from LDS for the fp64 coefficients
     else st = rho_eq ? vle_fast<true>(par, T, res, 1e-8, TOL_STEP) : vle_fast<true>(par, T, res);
 #else
     st = rho_eq ? vle_fast<false>(par, T, res, 1e-8, TOL_STEP) : vle_fast<false>(par, T, res);
@@ -443,7 +444,7 @@ int launch_pure_liquid_density(const double* params, const double* temp, const d
 #if PCS_PURE_PART == 1
 extern "C" {
 
-int pcs_abi_version(void) { return 103; }  // 103: pcs_pure_vapor_pressure, pcs_compact_* / pcs_expand_rows
+int pcs_abi_version(void) { return 104; }  // 103: pcs_pure_vapor_pressure, pcs_compact_* / pcs_expand_rows; 104: pcs_pure_vle_fp64
 
 const char* pcs_last_error(void) { return g_err; }
 
@@ -453,32 +454,30 @@ int64_t pcs_workspace_bytes(int64_t n) { return (int64_t)sizeof(int32_t) * (n + 
 // stage 1: zero the retry counter and run the fast kernel over all rows
 static int launch_vle_fast(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
                            double* rho_vl, uint8_t* status, int32_t* iters, int32_t* retry, hipStream_t s,
-                           bool force_lite = false) {
+                           bool force_lite = false, bool all_fp64 = false) {
     if (int ez = zero_ints(retry, 1, s)) return ez;
     hipError_t e;
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
-#ifdef PCS_F32_PRESOLVE
     // main kernel (lean: rows without an fp32 pre-solve go to the list with bit 31 set) + all-fp64 fallback kernel.
-    // LITE only for the pressure-only call: its densities are converged to ~1e-9 (enough for p*, whose error is of
-    // second order in them), while rho_eq and the Jacobian kernels (rho_vl) want the ~1e-12 of the D2 finish.
-    // (pcs_pure_vapor_pressure forces LITE and hands out those ~1e-9 densities: the property then has the same bits
-    // whether or not its caller also wants the Jacobian.)
-    if (!rho_eq && (!rho_vl || force_lite)) {
-        hipLaunchKernelGGL(k_pure_vle<true>, dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
+    //  * pressure only (and pcs_pure_vapor_pressure, whatever it hands out): k_pure_vle<true>, densities converged to ~1e-9
+    //    (enough for p*, whose error is of second order in them);
+    //  * rho_eq / rho_vl requested: the same kernel + the exact Newton update of vle_lite_finish<true> (round 3: 1.83 -> 1.22 ms
+    //    per 1e7 rows for equilibrium_liquid_density; until then the all-fp64 kernel);
+    //  * all_fp64 (pcs_pure_vle_fp64): k_pure_vle<false>, the fp64 D2 iteration from the fp32 pre-solve's start.
+    if (all_fp64) {
+        if (int ef = launch_pure_vle_full(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, s)) return ef;
+    } else if (!rho_eq && (!rho_vl || force_lite)) {
+        hipLaunchKernelGGL((k_pure_vle<true, false>), dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                            iters, retry);
-    } else if (int ef = launch_pure_vle_full(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, s)) {
-        return ef;
+    } else {
+        hipLaunchKernelGGL((k_pure_vle<true, true>), dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
+                           iters, retry);
     }
     hipLaunchKernelGGL(k_pure_vle_fallback, dim3(FALLBACK_GRID), dim3(64), 0, s, params, temp, p_sat, rho_eq, rho_vl, status,
                        iters, retry, n);
     e = hipGetLastError();
     if (e != hipSuccess) return fail("k_pure_vle launch", e);
     return 0;
-#else
-    (void)force_lite;
-    (void)e;
-    return launch_pure_vle_full(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, s);
-#endif
 }
 
 static int vle_args_ok(const double* params, const double* temp, int64_t n, const uint8_t* status,
@@ -495,6 +494,16 @@ int pcs_pure_vle(const double* params, const double* temp, int64_t n, double* p_
     if (n == 0) return 0;
     int32_t* retry = static_cast<int32_t*>(workspace);
     if (int e = launch_vle_fast(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, as_stream(stream))) return e;
+    return launch_vle_retry(params, temp, p_sat, rho_eq, rho_vl, status, iters, retry, n, as_stream(stream));
+}
+
+int pcs_pure_vle_fp64(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                      double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream) {
+    g_err[0] = 0;
+    if (int e = vle_args_ok(params, temp, n, status, workspace)) return e;
+    if (n == 0) return 0;
+    int32_t* retry = static_cast<int32_t*>(workspace);
+    if (int e = launch_vle_fast(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, as_stream(stream), false, true)) return e;
     return launch_vle_retry(params, temp, p_sat, rho_eq, rho_vl, status, iters, retry, n, as_stream(stream));
 }
 

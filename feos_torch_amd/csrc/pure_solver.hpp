@@ -245,6 +245,10 @@ PCS_DEV int vle_fast(const double* par, double T, VleResult& out, double tol_l =
 // 122 VGPRs / four waves per SIMD), lanes that fail afterwards ST_RETRY (robust pass).
 // vle_fast_lite = fp32 pre-solve (pure_f32.hpp) + vle_lite_finish; k_pure_vle<true> runs the two parts itself with the
 // block-level straggler exchange in between.
+// POLISH (densities requested: equilibrium_liquid_density, rho_vl for the Jacobians): one more update of both densities
+// with the exact dp/drho of an fp64 D2 evaluation at the converged state -- the iteration above leaves them at ~1e-9
+// (linear convergence with the fp32 slope), the exact Newton step squares that.  p* then carries the exact second-order term.
+template <bool POLISH = false>
 PCS_DEV int vle_lite_finish(const double* par, double T, bool warm, double rl, double rv, float dpl32, float dpv32,
                             VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
     PureCoef<double> c;
@@ -286,17 +290,34 @@ PCS_DEV int vle_lite_finish(const double* par, double T, bool warm, double rl, d
         if (__ballot(active && !done) == 0ull) break;
     }
     if (!warm || (active && !done)) return ST_FALLBACK;
+    if (POLISH) {
+        // accepted when the exact step is below 1e-7 (liquid) / 1e-6 (vapour): the updated densities are then converged to
+        // the square of that.  A lane whose linear iteration stopped further out (slow ratio close to the critical point)
+        // takes the all-fp64 iteration instead (ST_FALLBACK: k_pure_vle_fallback): no second step for the whole wave
+        if (done) {
+            const Eval pl = pure_eval(c, rl), pv = pure_eval(c, rv);
+            const VleStep s = vle_step(pl, pv, rl, rv);
+            rl += s.dl;
+            rv += s.dv;
+            if (!(is_finite_bits(s.p_corr) && fabs(s.dl) <= 1e-7 * rl && fabs(s.dv) <= 1e-6 * rv)) return ST_FALLBACK;
+            out.rho_l = rl;
+            out.rho_v = rv;
+            out.p_star = s.p_corr;
+            out.iters++;
+        }
+    }
     if (done && out.rho_v < 0.7 * out.rho_l && vapour_is_physical(out.p_star, out.rho_v)) return ST_OK;
     return ST_RETRY;
 }
 
+template <bool POLISH = false>
 PCS_DEV int vle_fast_lite(const double* par, double T, VleResult& out, double tol_l = TOL_L_P, double tol_v = TOL_V_P) {
     double rl = 0.0, rv = 0.0;
     float dpl32 = 1.0f, dpv32 = 1.0f;
     PureCoefF cf;
     pure_coef_f32(cf, par, T);
     const bool warm = vle_presolve_f32(cf, rl, rv, dpl32, dpv32);
-    return vle_lite_finish(par, T, warm, rl, rv, dpl32, dpv32, out, tol_l, tol_v);
+    return vle_lite_finish<POLISH>(par, T, warm, rl, rv, dpl32, dpv32, out, tol_l, tol_v);
 }
 #endif
 

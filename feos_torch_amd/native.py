@@ -45,10 +45,11 @@ def _same_rows(n, **named):
             raise ValueError(f"{name} has {t.shape[0]} rows, expected {n}")
 
 
-def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=False, want_rho_vl=True):
+def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=False, want_rho_vl=True, all_fp64=False):
     """Pure VLE on the GPU.  -> dict(p_sat [Pa], rho_eq [kmol/m3], rho_vl [n,2] A^-3, status bool, iters).
     want_rho_vl=False with want_rho_eq=False selects the pressure-only kernel (fp64 finish with the fp32
-    pre-solve's dp/drho; densities not returned)."""
+    pre-solve's dp/drho; densities not returned); with densities the same kernel adds one exact fp64 Newton update.
+    all_fp64: the validation twin (pcs_pure_vle_fp64: fp64 second derivatives in every iteration)."""
     device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
     params = _prep(params, device, (8,))
     temperature = _prep(temperature, device)
@@ -63,9 +64,10 @@ def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=Fal
         status = torch.empty(n, dtype=torch.uint8, device=device)
         iters = torch.empty(n, dtype=torch.int32, device=device) if want_iters else None
         ws = torch.empty(max(1, L.pcs_workspace_bytes(n) // 4), dtype=torch.int32, device=device)
-        rc = L.pcs_pure_vle(_lib.ptr(params), _lib.ptr(temperature), n, _lib.ptr(p_sat), _lib.ptr(rho_eq),
-                            _lib.ptr(rho_vl), _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws),
-                            _lib.current_stream_ptr(device))
+        fn = L.pcs_pure_vle_fp64 if all_fp64 else L.pcs_pure_vle
+        rc = fn(_lib.ptr(params), _lib.ptr(temperature), n, _lib.ptr(p_sat), _lib.ptr(rho_eq),
+                _lib.ptr(rho_vl), _lib.ptr(status), _lib.ptr(iters), _lib.ptr(ws),
+                _lib.current_stream_ptr(device))
         _lib.check(rc, "pcs_pure_vle")
     return {"p_sat": p_sat, "rho_eq": rho_eq, "rho_vl": rho_vl, "status": status.view(torch.bool), "iters": iters}
 
@@ -324,7 +326,8 @@ class PureVlePlan:
     current HIP stream (no allocation, no host synchronisation), so steps can be timed with
     HIP events."""
 
-    def __init__(self, n, device, want_rho_eq=False, want_rho_vl=False):
+    def __init__(self, n, device, want_rho_eq=False, want_rho_vl=False, all_fp64=False):
+        self.all_fp64 = bool(all_fp64)
         self.n = int(n)
         self.device = torch.device(device)
         self._L = _lib.lib()
@@ -342,7 +345,8 @@ class PureVlePlan:
                 _lib.current_stream_ptr(self.device))
 
     def run(self, params, temperature):
-        _lib.check(self._L.pcs_pure_vle(*self._args(params, temperature)), "pcs_pure_vle")
+        fn = self._L.pcs_pure_vle_fp64 if self.all_fp64 else self._L.pcs_pure_vle
+        _lib.check(fn(*self._args(params, temperature)), "pcs_pure_vle")
 
     def run_fast(self, params, temperature):
         _lib.check(self._L.pcs_pure_vle_fast(*self._args(params, temperature)), "pcs_pure_vle_fast")

@@ -51,6 +51,8 @@ int64_t pcs_workspace_bytes(int64_t n);
  *   status   [n]     out  uint8, 1 = failed
  *   iters    [n]     out  int32, Newton iterations used (optional, diagnostics)
  *   workspace        device scratch of pcs_workspace_bytes(n)
+ * Kernels: the fp32 pre-solve + fp64 finish of the pressure-only path; where rho_eq or rho_vl is requested the densities
+ * additionally take one exact fp64 Newton update (converged to ~1e-14; p_sat then carries that step's second-order term).
  */
 int pcs_pure_vle(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
                  double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);
@@ -69,12 +71,19 @@ int pcs_pure_vle_retry(const double* params, const double* temp, int64_t n, doub
                        double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);
 
 /*
+ * pcs_pure_vle with the all-fp64 main kernel (fp64 value / first / second derivative in every Newton iteration after the
+ * fp32 start) -- the validation twin of pcs_pure_vle: same arguments, same results to ~1e-11, ~1.3-2x the time.
+ */
+int pcs_pure_vle_fp64(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
+                      double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);
+
+/*
  * PcSaftPure.vapor_pressure as ONE call (feos_torch/pcsaft_pure.py:201-215 incl. its Rust solve, src/pcsaft.rs:82-103):
  * always the pressure-only kernel of pcs_pure_vle (fp32 pre-solve, fp64 finish), so p_sat carries the same bits whether
  * or not the caller also asks for the densities.
  *   rho_vl [n,2] out (optional) the densities the last fp64 Newton step of that kernel ended on: ~1e-9 (relative) from the
- *                root -- what the Jacobian kernel needs; p_sat is second order in that error.  For densities converged to
- *                ~1e-12 (the reference's rho output) call pcs_pure_vle with rho_vl.
+ *                root -- what the Jacobian kernel needs; p_sat is second order in that error.  For converged densities
+ *                (the reference's rho output) call pcs_pure_vle with rho_vl.
  */
 int pcs_pure_vapor_pressure(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_vl,
                             uint8_t* status, void* workspace, void* stream);

@@ -114,14 +114,16 @@ def test_kernel_stack_frames_and_occupancy(hip_lib):
             # direction through the fully inlined model, 4-25 KB of stack per lane for 1-6 components (not on any benchmark path)
             limit = 26 * 1024
         assert r["scratch"] <= limit, (name, r)
-    lite = [r for name, r in res.items() if "k_pure_vle<true>" in name]
+    lite = [r for name, r in res.items() if "k_pure_vle<true, false>" in name]
     assert len(lite) == 1 and lite[0]["scratch"] == 0 and lite[0]["occupancy"] >= 4, lite
+    polish = [r for name, r in res.items() if "k_pure_vle<true, true>" in name]  # + the exact Newton update of the densities
+    assert len(polish) == 1 and polish[0]["scratch"] <= 192 and polish[0]["occupancy"] >= 4, polish
     for which in range(3):
         jac = res[f"void k_pure_jacobian<{which}>"]
         assert jac["occupancy"] >= 2 and jac["scratch"] <= 256, (which, jac)
     # the all-fp64 VLE kernel and the liquid-density kernel trade a small spill frame for one / two more resident waves
     # (measured faster, csrc/pure_kernels.hip); the others use no stack
-    full = res["void k_pure_vle<false>"]
+    full = res["void k_pure_vle<false, false>"]
     assert full["occupancy"] >= 4 and full["scratch"] <= 320, full
     k2 = res["k_pure_liquid_density"]
     assert k2["occupancy"] >= 3 and k2["scratch"] <= 160, k2
