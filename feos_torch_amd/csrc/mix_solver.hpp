@@ -123,6 +123,12 @@ constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;
 constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double NEWTON_TRACE = 1e-4, NEWTON_TRACE_MAX = 100.0;  // see the Newton step below
 constexpr int NEWTON_MAX_IT = 60;
+// Largest step (in the logarithms of the three densities) at which the Newton iteration is accepted.  The state the two
+// evaluations were taken at is then within that of the solution, the densities handed out carry the step, and the
+// reference's final formula is second order in it: measured against 1e-9 (the value until round 3) on the 1e6-row batches
+// the pressures move by <= 1.0e-12 relative with 1e-7 (5e-11 with 1e-6: too much) and no failure mask changes; a wave of
+// the gc kernels no longer waits for the lanes that only needed the confirming iteration (gc bubble 1.76 -> 1.64 ms).
+constexpr double NEWTON_ACCEPT = 1e-7;
 // An iteration whose step has stopped shrinking below NEWTON_FLOOR (ratio >= 0.25) sits on the rounding floor of its residuals
 // (a trace component: the liquid's chemical potential of a component at x ~ 1e-13 carries ~1e-7 of noise) and is accepted;
 // the reference's final formula is second order in the remaining step (<= 1e-12).  1e-7 until round 3: rows cycling at

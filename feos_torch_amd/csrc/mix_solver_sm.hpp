@@ -407,7 +407,7 @@ struct BdLane {
             const bool stagnated = it >= 3 && mx < NEWTON_FLOOR && mx >= 0.25 * err_prev;
             err_prev = mx;
             it++;
-            if (mx <= 1e-9 || stagnated) {
+            if (mx <= NEWTON_ACCEPT || stagnated) {
                 const double dens_i = ri0 + ri1;
                 const double lo = DEW ? rs : dens_i, hi = DEW ? dens_i : rs;
                 stage = S_DONE;

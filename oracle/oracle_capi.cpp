@@ -409,7 +409,7 @@ void orc_mix_bubble_dew(const double* params, const double* kij, const double* T
             mix_bd_row<long double>(params + 16 * i, kij + 2 * i, T[i], z[i], p_init_pa[i], dew != 0, 1e-17L,
                                     rho4 ? rho4 + 4 * i : nullptr, p_out ? p_out + i : nullptr, status + i);
         else
-            mix_bd_row<double>(params + 16 * i, kij + 2 * i, T[i], z[i], p_init_pa[i], dew != 0, 1e-9,  // the kernels' Newton tolerance (csrc/mix_solver_sm.hpp): the double instantiation mirrors their decisions
+            mix_bd_row<double>(params + 16 * i, kij + 2 * i, T[i], z[i], p_init_pa[i], dew != 0, 1e-7,  // the kernels' Newton tolerance (NEWTON_ACCEPT, csrc/mix_solver.hpp): the double instantiation mirrors their decisions
                                
                                rho4 ? rho4 + 4 * i : nullptr, p_out ? p_out + i : nullptr, status + i);
     }
