@@ -114,15 +114,21 @@ constexpr int SS_MAX_IT = 40;
 // found its level; the Newton then starts in the dimerisation regime of a strongly associating trace component, where
 // d mu / d ln rho changes sign, and runs away)
 constexpr double SS_RES_TOL = 1e-2;
+// the substitution's secant step is taken where the residual of the map decreases along xi, however slowly (slope below this;
+// -0.05 until round 3: on a nearly flat map -- the liquid close to a liquid-liquid critical point -- the plain sweeps then
+// crept at dx ~ 2e-4 per sweep into the cap and the Newton started far from the solution); its length stays capped at ln 5
+// and the bracket of the fixed point stays in force
+constexpr double SS_SECANT_SLOPE = -1e-5;
 constexpr double SS_TOL = 1e-5;        // composition change at which the dew-point successive substitution hands over to Newton
 // A Newton iteration whose largest step has not shrunk by NEWTON_PROGRESS (relative to the smallest one so far) within
 // NEWTON_NO_PROGRESS iterations is given up: it cycles (typically a 2-cycle whose amplitude creeps down by 1e-3 per
 // round: no phase equilibrium at this state).  Bubble points start next to the solution (liquid root + ideal vapour)
 // and get the shorter leash; measured on the synthetic batches no converging row is lost by either.
-constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;
+constexpr int NEWTON_NO_PROGRESS = 20, NEWTON_NO_PROGRESS_BUBBLE = 15;  // dew: 30 until round 3 (now followed by the damped second run)
 constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double NEWTON_TRACE = 1e-4, NEWTON_TRACE_MAX = 100.0;  // see the Newton step below
 constexpr int NEWTON_MAX_IT = 60;
+constexpr int NEWTON_DAMPED_MAX_IT = 24, NEWTON_DAMPED_HALVINGS = 4;  // second, damped run of a failed dew-point Newton (mix_solver_sm.hpp)
 // Largest step (in the logarithms of the three densities) at which the Newton iteration is accepted.  The state the two
 // evaluations were taken at is then within that of the solution, the densities handed out carry the step, and the
 // reference's final formula is second order in it: measured against 1e-9 (the value until round 3) on the 1e6-row batches

@@ -66,6 +66,11 @@ struct BdLane {
     // Newton
     double rs, ri0, ri1, err_prev, err_best;
     int it, it_best;
+    // damped second run of the Newton stage (see newton_failed): the start of the stage, the largest correction of the last
+    // accepted iteration, the step that led to the current point, halvings of that step
+    bool damped;
+    int n_bt;
+    double rs0, ri00, ri10, m_prev, st0, st1, st2;
     PhaseEval sv;
     MixResult out;
 
@@ -104,8 +109,9 @@ struct BdLane {
         f0 = 0.0; rl0 = 0.0; x0 = z0; x1 = z1; p0 = p_init; rl = 0.0; xi_prev = 0.0; res_prev = 0.0; xi_lo = -1e300; xi_hi = 1e300;
         ss = 0;
         resolved = false;
-        rs = 0.0; ri0 = 0.0; ri1 = 0.0; err_prev = 1.0; err_best = 1e300;
-        it = 0; it_best = 0;
+        rs = 0.0; ri0 = 0.0; ri1 = 0.0;
+        damped = false; rs0 = ri00 = ri10 = 0.0;
+        reset_newton();
         sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
         out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
         out.iters = 0;
@@ -117,6 +123,33 @@ struct BdLane {
             raoult(m, fug1, rho1_);
         } else if (DEW) start_root(m, R_PURE0, 1.0, 0.0, 0.0, false, 0.0);
         else start_root(m, R_BUBBLE, z0, z1, p_init, true, 0.0);
+    }
+
+    PCS_DEV void reset_newton() {
+        err_prev = 1.0; err_best = 1e300;
+        it = 0; it_best = 0;
+        n_bt = 0; m_prev = 1e300; st0 = st1 = st2 = 0.0;
+    }
+    // the Newton stage starts at (rs, ri0, ri1)
+    PCS_DEV void enter_newton() {
+        rs0 = rs; ri00 = ri0; ri10 = ri1;
+        stage = S_NEWTON_S;
+    }
+    // The Newton stage has failed (singular step, no progress, collapse onto the trivial solution, iteration cap).  Dew
+    // points, plain form, full caps: one second run from the start of the stage with the natural monotonicity test -- where
+    // the correction at the new point is larger than the one that led there, half of the step is taken back (at most
+    // NEWTON_DAMPED_HALVINGS times in a row) -- and at most NEWTON_DAMPED_MAX_IT iterations.  It recovers rows whose
+    // substitution settles on the ideal-vapour fixed point of a nearly critical liquid, from where the plain iteration
+    // diverges or cycles (round 3: 24 of the 83 missed dew rows per 1e6; the first run is untouched, so no row is lost).
+    PCS_DEV void newton_failed() {
+        if (DEW && !robust && !damped && newton_max >= NEWTON_MAX_IT) {
+            damped = true;
+            rs = rs0; ri0 = ri00; ri1 = ri10;
+            reset_newton();
+            stage = S_NEWTON_S;
+        } else {
+            stage = S_DONE;  // rc = BD_FAILED
+        }
     }
 
     // Raoult's law from the pure-liquid fugacities (f0, f1) and the start of the successive substitution.  The liquid at the
@@ -149,12 +182,13 @@ struct BdLane {
         z0 = z0_; z1 = 1.0 - z0_; p_init = p_init_;
         ss_max = SS_MAX_IT; newton_max = NEWTON_MAX_IT;
         rc = BD_FAILED;
-        rs = rs_; ri0 = ri0_; ri1 = ri1_; err_prev = 1.0; err_best = 1e300;
-        it = 0; it_best = 0;
+        rs = rs_; ri0 = ri0_; ri1 = ri1_;
+        damped = false;
+        reset_newton();
         sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
         out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
         out.iters = 0;
-        stage = S_NEWTON_S;
+        enter_newton();
     }
 
     // INIT lanes: done, to be continued at the Newton iteration
@@ -279,7 +313,7 @@ struct BdLane {
                 rs = rho_new;
                 ri0 = (z0 * rs) * exp(g0c);  // ideal vapour at the liquid's fugacities
                 ri1 = (z1 * rs) * exp(g1c);
-                if (MODE == BD_MODE_INIT) handover(); else stage = S_NEWTON_S;
+                if (MODE == BD_MODE_INIT) handover(); else enter_newton();
                 return;
             }
             // R_SS: this evaluation (one tiny step away from the root) serves as the sweep's evaluation
@@ -319,7 +353,7 @@ struct BdLane {
             if (res < 0.0 && xi < xi_hi) xi_hi = xi;
             if (ss > 0 && xi != xi_prev) {
                 const double slope = (res - res_prev) / (xi - xi_prev);
-                if (slope < -0.05) {
+                if (slope < SS_SECANT_SLOPE) {
                     const double dxi = fmin(fmax(-res / slope, -1.6), 1.6);
                     const double ee = exp(xi + dxi);
                     x0 = ee / (1.0 + ee);
@@ -354,7 +388,7 @@ struct BdLane {
                 ri0 = x0 * rl;
                 ri1 = x1 * rl;
                 rs = p0;
-                if (MODE == BD_MODE_INIT) handover(); else stage = S_NEWTON_S;
+                if (MODE == BD_MODE_INIT) handover(); else enter_newton();
             }
             return;
         }
@@ -384,11 +418,23 @@ struct BdLane {
             A[1][3] = -(s.mu1() - n.mu1());
             A[2][3] = -(s.p() - n.p());
             double du[3];
-            if (!solve3(A, du)) { stage = S_DONE; return; }
+            if (!solve3(A, du)) { newton_failed(); return; }
             const double mx = fmax(fabs(du[0]), fmax(fabs(du[1]), fabs(du[2])));
-            if (!is_finite_bits(mx)) { stage = S_DONE; return; }
+            if (!is_finite_bits(mx)) { newton_failed(); return; }
+            if (damped) {
+                if (it > 0 && mx > m_prev && n_bt < NEWTON_DAMPED_HALVINGS && m_prev > 1e-3) {
+                    st0 *= 0.5; st1 *= 0.5; st2 *= 0.5;
+                    rs *= exp(-st0); ri0 *= exp(-st1); ri1 *= exp(-st2);
+                    n_bt++;
+                    it++;
+                    if (it >= NEWTON_DAMPED_MAX_IT) newton_failed(); else stage = S_NEWTON_S;
+                    return;
+                }
+                m_prev = mx;
+                n_bt = 0;
+            }
             if (mx < NEWTON_PROGRESS * err_best) { err_best = mx; it_best = it; }
-            else if (it - it_best >= (DEW ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE)) { stage = S_DONE; return; }
+            else if (it - it_best >= (DEW ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE)) { newton_failed(); return; }
             // at most a factor e per iteration -- except for a trace component of the incipient phase (mole fraction below
             // NEWTON_TRACE): its chemical potential is linear in ln rho_i there (ideal dilution), so the Newton step lands on
             // the solution however long it is and limiting it only makes the iteration march (rows with p ~ 1e-10 Pa and
@@ -397,30 +443,33 @@ struct BdLane {
             const bool tr0 = ri0 < NEWTON_TRACE * rtot, tr1 = ri1 < NEWTON_TRACE * rtot;
             const double mxl = fmax(fabs(du[0]), fmax(tr0 ? 0.0 : fabs(du[1]), tr1 ? 0.0 : fabs(du[2])));
             const double scale = mxl > 1.0 ? 1.0 / mxl : 1.0;
-            rs *= exp(scale * du[0]);
-            ri0 *= exp(tr0 ? fmin(fmax(du[1], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[1]);
-            ri1 *= exp(tr1 ? fmin(fmax(du[2], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[2]);
+            st0 = scale * du[0];
+            st1 = tr0 ? fmin(fmax(du[1], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[1];
+            st2 = tr1 ? fmin(fmax(du[2], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[2];
+            rs *= exp(st0);
+            ri0 *= exp(st1);
+            ri1 *= exp(st2);
             out.iters = it + 1;
             // the iteration has collapsed onto the trivial solution (both phases identical): the Jacobian is singular there
             // and the steps wander along its null direction until a cap stops them -> give the row up now
-            if (fabs(ri0 + ri1 - rs) <= 1e-6 * rs && fabs(ri0 - z0 * rs) <= 1e-6 * rs) { stage = S_DONE; return; }
+            if (fabs(ri0 + ri1 - rs) <= 1e-6 * rs && fabs(ri0 - z0 * rs) <= 1e-6 * rs) { newton_failed(); return; }
             const bool stagnated = it >= 3 && mx < NEWTON_FLOOR && mx >= 0.25 * err_prev;
             err_prev = mx;
             it++;
             if (mx <= NEWTON_ACCEPT || stagnated) {
                 const double dens_i = ri0 + ri1;
                 const double lo = DEW ? rs : dens_i, hi = DEW ? dens_i : rs;
+                if (!(lo < hi * (1.0 - 1e-6))) { newton_failed(); return; }  // trivial solution
                 stage = S_DONE;
-                if (!(lo < hi * (1.0 - 1e-6))) return;  // trivial solution
                 // converged: the state these two evaluations were taken at is within mx of the solution and the
                 // reference's final formula is second order in that error, so it is applied to them directly (no
                 // further evaluation); the densities handed out carry the last step
                 out.spec0 = z0 * rs; out.spec1 = z1 * rs; out.inc0 = ri0; out.inc1 = ri1;
                 out.p = bubble_dew_formula(s, n);
                 rc = is_finite_bits(out.p) ? BD_OK : BD_FAILED;
-            } else if (it >= newton_max) {
-                rc = (newton_max < NEWTON_MAX_IT) ? BD_CAP : BD_FAILED;
-                stage = S_DONE;
+            } else if (it >= (damped ? NEWTON_DAMPED_MAX_IT : newton_max)) {
+                if (newton_max < NEWTON_MAX_IT) { rc = BD_CAP; stage = S_DONE; }
+                else newton_failed();
             } else {
                 stage = S_NEWTON_S;
             }
@@ -489,7 +538,7 @@ PCS_DEV void pure_fugacities_on_the_line(const Model& m, double fug[2], double r
 // + 2 evaluations per Newton iteration.  Every driver of the state machine (single pass below, work queue in
 // mix_kernels.hip) gives a row up beyond it, so a stage transition that fails to advance a counter fails the row
 // instead of hanging the wave.
-constexpr int BD_EVAL_GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MAX_IT + 2) + 2 * NEWTON_MAX_IT + 8;
+constexpr int BD_EVAL_GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MAX_IT + 2) + 2 * (NEWTON_MAX_IT + NEWTON_DAMPED_MAX_IT) + 8;
 
 // One row per lane: every pass of the wave-level loop evaluates once for every unfinished lane.
 // Two attempts: the plain form, then -- only if one of its liquid roots failed -- the robust form (try_robust).

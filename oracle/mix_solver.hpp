@@ -71,10 +71,12 @@ PhaseEval<F> eval_phase(const Model& model, F T, const F* rho) {
 // the scaled function is nearly linear).  Only used to initialise the phase-equilibrium Newton, so
 // a relative step of LIQ_ROOT_TOL suffices.  Same logic and caps as csrc/mix_solver.hpp.
 constexpr double LIQ_ROOT_TOL = 1e-3;  // as csrc/mix_solver.hpp
-constexpr int NEWTON_NO_PROGRESS = 30, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
+constexpr int NEWTON_NO_PROGRESS = 20, NEWTON_NO_PROGRESS_BUBBLE = 15;  // as csrc/mix_solver.hpp
 constexpr double NEWTON_PROGRESS = 0.9;
 constexpr double NEWTON_TRACE = 1e-4, NEWTON_TRACE_MAX = 100.0;
 constexpr double SS_RES_TOL = 1e-2;     // as csrc/mix_solver.hpp
+constexpr double SS_SECANT_SLOPE = -1e-5;  // as csrc/mix_solver.hpp: the secant step wherever the map's residual decreases along xi
+constexpr int NEWTON_DAMPED_MAX_IT = 24, NEWTON_DAMPED_HALVINGS = 4;  // as csrc/mix_solver.hpp
 constexpr double NEWTON_FLOOR = 1e-6;  // as csrc/mix_solver.hpp: a step that has stopped shrinking below it sits on the rounding floor and is accepted
 constexpr double SS_TOL = 1e-5;  // composition change at which the dew-point successive substitution hands over to Newton
 // Robust form of the liquid root (second pass of the solvers, csrc/mix_solver.hpp: ROBUST): a bracket [lo, hi] with
@@ -200,6 +202,99 @@ struct MixSolveInfo {
 
 // z = mole fraction of component 1 in the specified phase; p_init [reduced] = caller's initial
 // pressure (src/pcsaft.rs:174 passes it to feos as Some(p)).  Outputs partial densities.
+// The Newton stage of bubble_dew from (rs, ri): in (ln rho_spec, ln rho_inc_1, ln rho_inc_2).  damped: with the natural
+// monotonicity test (second attempt of a row whose plain iteration failed, see bubble_dew)
+template <class F, class Model>
+bool newton_stage(const Model& model, F T, const F* z, bool dew, F rs, F ri0, F ri1, F* rho_spec, F* rho_inc, MixSolveInfo& info,
+                  F tol, bool damped) {
+    F ri[2] = {ri0, ri1};
+    const bool bt_on = damped;
+    // Newton in (ln rho_spec, ln rho_inc_1, ln rho_inc_2)
+    F err_prev = F(1), err_best = F(1e300);
+    int it_best = 0;
+    const int no_progress = getenv("ORC_NP") ? atoi(getenv("ORC_NP")) : (dew ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE);
+    F m_prev = F(1e300), st_prev[3] = {F(0), F(0), F(0)};
+    int n_bt = 0;
+    for (int it = 0; it < (damped ? NEWTON_DAMPED_MAX_IT : 60); it++) {
+        F r_s[2] = {z[0] * rs, z[1] * rs};
+        PhaseEval<F> s = eval_phase<F>(model, T, r_s);
+        PhaseEval<F> n = eval_phase<F>(model, T, ri);
+        F Fv[3] = {s.mu(0) - n.mu(0), s.mu(1) - n.mu(1), s.p() - n.p()};
+        F J[3][3];
+        for (int i = 0; i < 2; i++) {
+            J[i][0] = rs * (z[0] * s.dmu(i, 0) + z[1] * s.dmu(i, 1));
+            J[i][1] = -ri[0] * n.dmu(i, 0);
+            J[i][2] = -ri[1] * n.dmu(i, 1);
+        }
+        J[2][0] = rs * (z[0] * s.dp(0) + z[1] * s.dp(1));
+        J[2][1] = -ri[0] * n.dp(0);
+        J[2][2] = -ri[1] * n.dp(1);
+        F rhs[3] = {-Fv[0], -Fv[1], -Fv[2]}, du[3];
+        if (!solve3<F>(J, rhs, du)) return false;
+        F mx = 0;
+        for (int k = 0; k < 3; k++) { F a = du[k] < 0 ? -du[k] : du[k]; if (a > mx) mx = a; }
+        if (!(mx == mx)) return false;
+        if (bt_on) {
+            const double bt_theta = 1.0;
+            const int bt_max = NEWTON_DAMPED_HALVINGS;
+            // natural monotonicity test: the Newton correction at the new point is larger than the one that led there --
+            // the step overshot: take half of it back and look again
+            if (it > 0 && mx > F(bt_theta) * m_prev && n_bt < bt_max && m_prev > F(1e-3)) {
+                for (int k = 0; k < 3; k++) st_prev[k] = F(0.5) * st_prev[k];
+                rs = rs * exp(-st_prev[0]);
+                ri[0] = ri[0] * exp(-st_prev[1]);
+                ri[1] = ri[1] * exp(-st_prev[2]);
+                n_bt++;
+                if (getenv("ORC_TRACE")) fprintf(stderr, "it %d backtrack %d mx %.3e > %.3e\n", it, n_bt, (double)mx, (double)m_prev);
+                continue;
+            }
+            m_prev = mx;
+            n_bt = 0;
+        }
+        // no new smallest Newton step for NEWTON_NO_PROGRESS iterations: the iteration cycles / wanders
+        // (no phase equilibrium at this state, or the EOS is ill-behaved there) -> fail now, not at the cap
+        static const double np_factor = getenv("ORC_NP_FACTOR") ? atof(getenv("ORC_NP_FACTOR")) : NEWTON_PROGRESS;
+        if (mx < F(np_factor) * err_best) { err_best = mx; it_best = it; }
+        else if (it - it_best >= no_progress) return false;
+        // at most a factor e per iteration -- except for a trace component of the incipient phase (mole fraction
+        // below NEWTON_TRACE): its chemical potential is linear in ln rho_i there (ideal dilution), the Newton step
+        // lands on the solution however long it is, and limiting it would only make the iteration march
+        static const bool trace_rule = getenv("ORC_NO_TRACE") == nullptr;
+        F rtot = ri[0] + ri[1];
+        bool tr0 = trace_rule && ri[0] < F(NEWTON_TRACE) * rtot, tr1 = trace_rule && ri[1] < F(NEWTON_TRACE) * rtot;
+        F mxl = du[0] < 0 ? -du[0] : du[0];
+        if (!tr0) { F a = du[1] < 0 ? -du[1] : du[1]; if (a > mxl) mxl = a; }
+        if (!tr1) { F a = du[2] < 0 ? -du[2] : du[2]; if (a > mxl) mxl = a; }
+        F scale = mxl > F(1) ? F(1) / mxl : F(1);
+        F s0 = scale * du[1], s1 = scale * du[2];
+        if (tr0) s0 = du[1] > F(NEWTON_TRACE_MAX) ? F(NEWTON_TRACE_MAX) : (du[1] < F(-NEWTON_TRACE_MAX) ? F(-NEWTON_TRACE_MAX) : du[1]);
+        if (tr1) s1 = du[2] > F(NEWTON_TRACE_MAX) ? F(NEWTON_TRACE_MAX) : (du[2] < F(-NEWTON_TRACE_MAX) ? F(-NEWTON_TRACE_MAX) : du[2]);
+        rs = rs * exp(scale * du[0]);
+        ri[0] = ri[0] * exp(s0);
+        ri[1] = ri[1] * exp(s1);
+        st_prev[0] = scale * du[0]; st_prev[1] = s0; st_prev[2] = s1;
+        if (getenv("ORC_TRACE")) fprintf(stderr, "it %d mx %.3e du %.3e %.3e %.3e rs %.6e ri %.6e %.6e F %.3e %.3e %.3e\n", it, (double)mx, (double)du[0], (double)du[1], (double)du[2], (double)rs, (double)ri[0], (double)ri[1], (double)Fv[0], (double)Fv[1], (double)Fv[2]);
+        info.iters = it + 1;
+        {   // collapsed onto the trivial solution (both phases identical, singular Jacobian): give up (as csrc/mix_solver.hpp)
+            F dtot = ri[0] + ri[1] - rs, d0 = ri[0] - z[0] * rs;
+            if ((dtot < 0 ? -dtot : dtot) <= F(1e-6) * rs && (d0 < 0 ? -d0 : d0) <= F(1e-6) * rs) return false;
+        }
+        bool stagnated = it >= 3 && mx < F(NEWTON_FLOOR) && mx >= F(0.25) * err_prev;
+        err_prev = mx;
+        if (mx <= tol || stagnated) {
+            F dens_s = rs, dens_i = ri[0] + ri[1];
+            F lo = dew ? dens_s : dens_i, hi = dew ? dens_i : dens_s;  // vapour, liquid
+            if (!(lo < hi * (F(1) - F(1e-6)))) return false;           // trivial solution
+            rho_spec[0] = z[0] * rs;
+            rho_spec[1] = z[1] * rs;
+            rho_inc[0] = ri[0];
+            rho_inc[1] = ri[1];
+            return true;
+        }
+    }
+    return false;
+}
+
 template <class F, class Model>
 bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, F* rho_inc, MixSolveInfo& info, F tol,
                 bool robust = false) {
@@ -317,7 +412,8 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
             }
             if (ss_secant && ss > 0 && xi != xi_prev) {
                 F slope = (res - res_prev) / (xi - xi_prev);
-                if (slope < F(-0.05)) {
+                static const double ss_slope = getenv("ORC_SS_SLOPE") ? atof(getenv("ORC_SS_SLOPE")) : SS_SECANT_SLOPE;
+                if (slope < F(ss_slope)) {
                     F dxi = -res / slope;
                     if (dxi > F(1.6)) dxi = F(1.6);
                     if (dxi < F(-1.6)) dxi = F(-1.6);
@@ -367,69 +463,12 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
         ri[1] = x[1] * rl;
         rs = p0;  // ideal vapour
     }
-    // Newton in (ln rho_spec, ln rho_inc_1, ln rho_inc_2)
-    F err_prev = F(1), err_best = F(1e300);
-    int it_best = 0;
-    const int no_progress = getenv("ORC_NP") ? atoi(getenv("ORC_NP")) : (dew ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE);
-    for (int it = 0; it < 60; it++) {
-        F r_s[2] = {z[0] * rs, z[1] * rs};
-        PhaseEval<F> s = eval_phase<F>(model, T, r_s);
-        PhaseEval<F> n = eval_phase<F>(model, T, ri);
-        F Fv[3] = {s.mu(0) - n.mu(0), s.mu(1) - n.mu(1), s.p() - n.p()};
-        F J[3][3];
-        for (int i = 0; i < 2; i++) {
-            J[i][0] = rs * (z[0] * s.dmu(i, 0) + z[1] * s.dmu(i, 1));
-            J[i][1] = -ri[0] * n.dmu(i, 0);
-            J[i][2] = -ri[1] * n.dmu(i, 1);
-        }
-        J[2][0] = rs * (z[0] * s.dp(0) + z[1] * s.dp(1));
-        J[2][1] = -ri[0] * n.dp(0);
-        J[2][2] = -ri[1] * n.dp(1);
-        F rhs[3] = {-Fv[0], -Fv[1], -Fv[2]}, du[3];
-        if (!solve3<F>(J, rhs, du)) return false;
-        F mx = 0;
-        for (int k = 0; k < 3; k++) { F a = du[k] < 0 ? -du[k] : du[k]; if (a > mx) mx = a; }
-        if (!(mx == mx)) return false;
-        // no new smallest Newton step for NEWTON_NO_PROGRESS iterations: the iteration cycles / wanders
-        // (no phase equilibrium at this state, or the EOS is ill-behaved there) -> fail now, not at the cap
-        static const double np_factor = getenv("ORC_NP_FACTOR") ? atof(getenv("ORC_NP_FACTOR")) : NEWTON_PROGRESS;
-        if (mx < F(np_factor) * err_best) { err_best = mx; it_best = it; }
-        else if (it - it_best >= no_progress) return false;
-        // at most a factor e per iteration -- except for a trace component of the incipient phase (mole fraction
-        // below NEWTON_TRACE): its chemical potential is linear in ln rho_i there (ideal dilution), the Newton step
-        // lands on the solution however long it is, and limiting it would only make the iteration march
-        static const bool trace_rule = getenv("ORC_NO_TRACE") == nullptr;
-        F rtot = ri[0] + ri[1];
-        bool tr0 = trace_rule && ri[0] < F(NEWTON_TRACE) * rtot, tr1 = trace_rule && ri[1] < F(NEWTON_TRACE) * rtot;
-        F mxl = du[0] < 0 ? -du[0] : du[0];
-        if (!tr0) { F a = du[1] < 0 ? -du[1] : du[1]; if (a > mxl) mxl = a; }
-        if (!tr1) { F a = du[2] < 0 ? -du[2] : du[2]; if (a > mxl) mxl = a; }
-        F scale = mxl > F(1) ? F(1) / mxl : F(1);
-        F s0 = scale * du[1], s1 = scale * du[2];
-        if (tr0) s0 = du[1] > F(NEWTON_TRACE_MAX) ? F(NEWTON_TRACE_MAX) : (du[1] < F(-NEWTON_TRACE_MAX) ? F(-NEWTON_TRACE_MAX) : du[1]);
-        if (tr1) s1 = du[2] > F(NEWTON_TRACE_MAX) ? F(NEWTON_TRACE_MAX) : (du[2] < F(-NEWTON_TRACE_MAX) ? F(-NEWTON_TRACE_MAX) : du[2]);
-        rs = rs * exp(scale * du[0]);
-        ri[0] = ri[0] * exp(s0);
-        ri[1] = ri[1] * exp(s1);
-        if (getenv("ORC_TRACE")) fprintf(stderr, "it %d mx %.3e du %.3e %.3e %.3e rs %.6e ri %.6e %.6e F %.3e %.3e %.3e\n", it, (double)mx, (double)du[0], (double)du[1], (double)du[2], (double)rs, (double)ri[0], (double)ri[1], (double)Fv[0], (double)Fv[1], (double)Fv[2]);
-        info.iters = it + 1;
-        {   // collapsed onto the trivial solution (both phases identical, singular Jacobian): give up (as csrc/mix_solver.hpp)
-            F dtot = ri[0] + ri[1] - rs, d0 = ri[0] - z[0] * rs;
-            if ((dtot < 0 ? -dtot : dtot) <= F(1e-6) * rs && (d0 < 0 ? -d0 : d0) <= F(1e-6) * rs) return false;
-        }
-        bool stagnated = it >= 3 && mx < F(NEWTON_FLOOR) && mx >= F(0.25) * err_prev;
-        err_prev = mx;
-        if (mx <= tol || stagnated) {
-            F dens_s = rs, dens_i = ri[0] + ri[1];
-            F lo = dew ? dens_s : dens_i, hi = dew ? dens_i : dens_s;  // vapour, liquid
-            if (!(lo < hi * (F(1) - F(1e-6)))) return false;           // trivial solution
-            rho_spec[0] = z[0] * rs;
-            rho_spec[1] = z[1] * rs;
-            rho_inc[0] = ri[0];
-            rho_inc[1] = ri[1];
-            return true;
-        }
-    }
+    // Newton from there; a row whose iteration fails (it diverges or cycles from the ideal-vapour fixed point of the
+    // substitution: a nearly critical liquid) gets a second, damped run from the same start (dew points)
+    const F rs0 = rs, ri00 = ri[0], ri10 = ri[1];
+    if (newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, false)) return true;
+    static const bool damped_retry = getenv("ORC_NO_DAMPED") == nullptr;
+    if (damped_retry && dew && !robust) return newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, true);
     return false;
 }
 
