@@ -68,7 +68,7 @@ struct BdLane {
     int it, it_best;
     // damped second run of the Newton stage (see newton_failed): the start of the stage, the largest correction of the last
     // accepted iteration, the step that led to the current point, halvings of that step
-    bool damped;
+    bool damped, may_damp;  // may_damp: the driver allows the damped run (set by start / start_newton; the gc kernels clear it)
     int n_bt;
     double rs0, ri00, ri10, m_prev, st0, st1, st2;
     PhaseEval sv;
@@ -110,7 +110,7 @@ struct BdLane {
         ss = 0;
         resolved = false;
         rs = 0.0; ri0 = 0.0; ri1 = 0.0;
-        damped = false; rs0 = ri00 = ri10 = 0.0;
+        damped = false; may_damp = true; rs0 = ri00 = ri10 = 0.0;
         reset_newton();
         sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
         out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
@@ -142,7 +142,7 @@ struct BdLane {
     // substitution settles on the ideal-vapour fixed point of a nearly critical liquid, from where the plain iteration
     // diverges or cycles (round 3: 24 of the 83 missed dew rows per 1e6; the first run is untouched, so no row is lost).
     PCS_DEV void newton_failed() {
-        if (DEW && !robust && !damped && newton_max >= NEWTON_MAX_IT) {
+        if (DEW && may_damp && !robust && !damped && newton_max >= NEWTON_MAX_IT) {
             damped = true;
             rs = rs0; ri0 = ri00; ri1 = ri10;
             reset_newton();
@@ -183,7 +183,7 @@ struct BdLane {
         ss_max = SS_MAX_IT; newton_max = NEWTON_MAX_IT;
         rc = BD_FAILED;
         rs = rs_; ri0 = ri0_; ri1 = ri1_;
-        damped = false;
+        damped = false; may_damp = true;
         reset_newton();
         sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
         out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
@@ -545,10 +545,11 @@ constexpr int BD_EVAL_GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MA
 template <bool DEW, class Model>
 PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
                                 int newton_max = NEWTON_MAX_IT, bool robust = false, bool* root_failed = nullptr,
-                                const double* fug = nullptr, const double* rho_pure = nullptr) {
+                                const double* fug = nullptr, const double* rho_pure = nullptr, bool may_damp = true) {
     BdLane<DEW> L;
     if (fug) L.start(m, z0, p_init, ss_max, newton_max, robust, fug[0], fug[1], rho_pure[0], rho_pure[1]);
     else L.start(m, z0, p_init, ss_max, newton_max, robust);
+    L.may_damp = may_damp;
     for (int guard = 0; guard < (robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD); guard++) {
         if (__ballot(!L.done()) == 0ull) break;
         if (L.done()) continue;

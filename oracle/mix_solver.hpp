@@ -297,7 +297,7 @@ bool newton_stage(const Model& model, F T, const F* z, bool dew, F rs, F ri0, F 
 
 template <class F, class Model>
 bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, F* rho_inc, MixSolveInfo& info, F tol,
-                bool robust = false) {
+                bool robust = false, bool may_damp = true) {
     F z[2] = {z1, F(1) - z1};
     F rs, ri[2];  // total density of the specified phase, partial densities of the incipient one
     info.iters = 0;
@@ -468,7 +468,7 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
     const F rs0 = rs, ri00 = ri[0], ri10 = ri[1];
     if (newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, false)) return true;
     static const bool damped_retry = getenv("ORC_NO_DAMPED") == nullptr;
-    if (damped_retry && dew && !robust) return newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, true);
+    if (damped_retry && may_damp && dew && !robust) return newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, true);
     return false;
 }
 

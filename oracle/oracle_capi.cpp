@@ -540,7 +540,8 @@ void gc_bd_row(GcRow& r, double T, double z, double p_pa, bool dew, F tol, doubl
     F rs[2], ri[2];
     MixSolveInfo info;
     F p_red = F(p_pa) / F(T) * F(1.0 / P_UNIT);
-    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol) || (info.root_failed && bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true));
+    // (no damped second run of the Newton stage for gc rows: as csrc/gc_kernels.hip)
+    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, false, false) || (info.root_failed && bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true));
     *status = ok ? 0 : 1;
     const F* v = dew ? rs : ri;
     const F* l = dew ? ri : rs;
