@@ -221,15 +221,10 @@ def main():
         }
     if world == 1 and not args.no_extra:
         variants = {}
-        fp64 = native.PureVlePlan(rows, device, want_rho_vl=True, all_fp64=True)  # validation twin: k_pure_vle<false>
-        t_f = timed(lambda _i: fp64.run(Pd, Td))
+        full = native.PureVlePlan(rows, device, want_rho_vl=True)  # all-fp64 kernel k_pure_vle<false>, returns the densities
+        t_f = timed(lambda _i: full.run(Pd, Td))
         variants["all_fp64_kernel"] = {"value": rows * steps / t_f, "ms_per_step": t_f / steps * 1e3,
-                                       "what": "pcs_pure_vle_fp64 (k_pure_vle<false>): fp64 D2 iteration, p_sat + (rho_V, rho_L) returned"}
-        del fp64
-        full = native.PureVlePlan(rows, device, want_rho_vl=True)  # pressure-only kernel + exact Newton update of the densities
-        t_d = timed(lambda _i: full.run(Pd, Td))
-        variants["with_densities"] = {"value": rows * steps / t_d, "ms_per_step": t_d / steps * 1e3,
-                                      "what": "pcs_pure_vle with rho_vl (k_pure_vle<true, polish>): p_sat + converged (rho_V, rho_L)"}
+                                       "what": "k_pure_vle<false>: fp64 D2 finish, p_sat + (rho_V, rho_L) returned"}
 
         def fwd_jac(_i):
             full.run(Pd, Td)
@@ -237,7 +232,7 @@ def main():
 
         t_j = timed(fwd_jac)
         variants["forward_plus_jacobian"] = {"value": rows * steps / t_j, "ms_per_step": t_j / steps * 1e3,
-                                             "what": "solve with densities + k_pure_jacobian<0>: d p_sat / d(8 parameters, T) per row"}
+                                             "what": "all-fp64 solve + k_pure_jacobian<0>: d p_sat / d(8 parameters, T) per row"}
         del full
         from feos_torch_amd import PcSaftPure
 

@@ -461,12 +461,14 @@ static int launch_vle_fast(const double* params, const double* temp, int64_t n, 
     // main kernel (lean: rows without an fp32 pre-solve go to the list with bit 31 set) + all-fp64 fallback kernel.
     //  * pressure only (and pcs_pure_vapor_pressure, whatever it hands out): k_pure_vle<true>, densities converged to ~1e-9
     //    (enough for p*, whose error is of second order in them);
-    //  * rho_eq / rho_vl requested: the same kernel + the exact Newton update of vle_lite_finish<true> (round 3: 1.83 -> 1.22 ms
-    //    per 1e7 rows for equilibrium_liquid_density; until then the all-fp64 kernel);
-    //  * all_fp64 (pcs_pure_vle_fp64): k_pure_vle<false>, the fp64 D2 iteration from the fp32 pre-solve's start.
-    if (all_fp64) {
+    //  * rho_vl without rho_eq (the Jacobian kernels' input), and everything under all_fp64 (pcs_pure_vle_fp64):
+    //    k_pure_vle<false>, the fp64 D2 iteration from the fp32 pre-solve's start -- one iteration at the pressure
+    //    tolerances, densities ~1e-11 (0.945 ms per 1e7 rows against 0.990 for the next form);
+    //  * rho_eq requested (tolerance 1e-8 on the liquid step: two D2 iterations of the all-fp64 kernel, 1.55-1.67 ms): the
+    //    pressure-only kernel + the exact Newton update of vle_lite_finish<true> instead, 1.22 ms (round 3).
+    if (all_fp64 || (!rho_eq && rho_vl && !force_lite)) {
         if (int ef = launch_pure_vle_full(params, temp, n, p_sat, rho_eq, rho_vl, status, iters, retry, s)) return ef;
-    } else if (!rho_eq && (!rho_vl || force_lite)) {
+    } else if (!rho_eq) {
         hipLaunchKernelGGL((k_pure_vle<true, false>), dim3(grid), dim3(BLOCK), 0, s, params, temp, n, p_sat, rho_eq, rho_vl, status,
                            iters, retry);
     } else {

@@ -48,7 +48,8 @@ def _same_rows(n, **named):
 def pure_vle(params, temperature, want_p=True, want_rho_eq=False, want_iters=False, want_rho_vl=True, all_fp64=False):
     """Pure VLE on the GPU.  -> dict(p_sat [Pa], rho_eq [kmol/m3], rho_vl [n,2] A^-3, status bool, iters).
     want_rho_vl=False with want_rho_eq=False selects the pressure-only kernel (fp64 finish with the fp32
-    pre-solve's dp/drho; densities not returned); with densities the same kernel adds one exact fp64 Newton update.
+    pre-solve's dp/drho; densities not returned); rho_vl: the all-fp64 kernel; rho_eq: pressure-only kernel + one exact fp64
+    Newton update of the densities.
     all_fp64: the validation twin (pcs_pure_vle_fp64: fp64 second derivatives in every iteration)."""
     device = params.device if isinstance(params, torch.Tensor) and params.is_cuda else _dev()
     params = _prep(params, device, (8,))

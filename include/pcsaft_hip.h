@@ -51,8 +51,9 @@ int64_t pcs_workspace_bytes(int64_t n);
  *   status   [n]     out  uint8, 1 = failed
  *   iters    [n]     out  int32, Newton iterations used (optional, diagnostics)
  *   workspace        device scratch of pcs_workspace_bytes(n)
- * Kernels: the fp32 pre-solve + fp64 finish of the pressure-only path; where rho_eq or rho_vl is requested the densities
- * additionally take one exact fp64 Newton update (converged to ~1e-14; p_sat then carries that step's second-order term).
+ * Kernels: pressure only -- fp32 pre-solve + fp64 finish with the pre-solve's dp/drho; rho_vl -- the all-fp64 iteration from
+ * the pre-solve's start (densities ~1e-11); rho_eq -- the pressure-only path + one exact fp64 Newton update of both densities
+ * (~1e-14; p_sat then carries that step's second-order term).
  */
 int pcs_pure_vle(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
                  double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);
@@ -72,7 +73,7 @@ int pcs_pure_vle_retry(const double* params, const double* temp, int64_t n, doub
 
 /*
  * pcs_pure_vle with the all-fp64 main kernel (fp64 value / first / second derivative in every Newton iteration after the
- * fp32 start) -- the validation twin of pcs_pure_vle: same arguments, same results to ~1e-11, ~1.3-2x the time.
+ * fp32 start) whatever the outputs -- the validation twin of pcs_pure_vle: same arguments, same results to ~1e-11.
  */
 int pcs_pure_vle_fp64(const double* params, const double* temp, int64_t n, double* p_sat, double* rho_eq,
                       double* rho_vl, uint8_t* status, int32_t* iters, void* workspace, void* stream);

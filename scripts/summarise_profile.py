@@ -52,7 +52,7 @@ def short(k):
 
 
 def is_headline(k):
-    return "k_pure_vle<true>" in k or "k_pure_vle<(bool)1>" in k
+    return "k_pure_vle<true, false>" in k or "k_pure_vle<true>" in k or "k_pure_vle<(bool)1, (bool)0>" in k
 
 
 stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)  # newest: gpurun merges runs
@@ -173,7 +173,7 @@ for k, c in allc.items():
                    "issue_ns": issue_ns, "simd_ns": simd_ns, "frac": frac}
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 if traffic is not None:
-    out = {"tag": tag, "kernel": "k_pure_vle<true>", "rows": 10_000_000, "hbm_bytes_per_launch": traffic,
+    out = {"tag": tag, "kernel": "k_pure_vle<true, false>", "rows": 10_000_000, "hbm_bytes_per_launch": traffic,
            "valu_wave_instr_per_launch": valu_instr, "kernel_ms_timed_launches": kernel_ms,
            "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH correction"}
     if mix_out:
