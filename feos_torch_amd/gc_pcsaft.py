@@ -18,6 +18,7 @@ that one non-differentiable term is left out and everything else is finite.)
 """
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import native
 
@@ -168,6 +169,7 @@ class _GcDerivatives(torch.autograd.Function):
         return a.to(out), p.to(out), mu.to(out), v.to(out)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_a, g_p, g_mu, g_v):
         table, rows, ph, T, rho = ctx.saved_tensors
         nseg = len(ctx.seg_devs)
@@ -228,6 +230,7 @@ class _GcBubbleDew(torch.autograd.Function):
         return value.to(out_device), nans
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_value, _g):
         nseg = len(ctx.seg_needs)
         if not ctx.saved:  # nothing the pressure depends on required a gradient

@@ -10,6 +10,7 @@ Two layers:
 """
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -187,6 +188,7 @@ class _CompactRows(torch.autograd.Function):
         return comp.gather(x.detach().to(comp.device)).to(x.device)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         comp = ctx.comp
         g = g.to(comp.device).contiguous()

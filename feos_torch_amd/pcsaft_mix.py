@@ -10,6 +10,7 @@ does not depend on the mole fractions or the initial pressure explicitly, so tho
 zero gradient there; here they receive none).
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import native
 
@@ -45,6 +46,7 @@ class _BubbleDew(torch.autograd.Function):
         return value.to(out_device), nans
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_value, _g_nans):
         (jac,) = ctx.saved_tensors
         comp = ctx.comp
@@ -79,6 +81,7 @@ class _MixDerivatives(torch.autograd.Function):
         return a.to(out), p.to(out), mu.to(out), v.to(out)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_a, g_p, g_mu, g_v):
         par, k, T, rho = ctx.saved_tensors
         if g_a is None and g_p is None and g_mu is None and g_v is None:
@@ -109,6 +112,7 @@ class _MixnDerivatives(torch.autograd.Function):
         return a.to(out), p.to(out), mu.to(out), v.to(out)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_a, g_p, g_mu, g_v):
         par, T, rho = ctx.saved_tensors
         if g_a is None and g_p is None and g_mu is None and g_v is None:

@@ -14,6 +14,7 @@ Tensors may live on any device; the computation runs on the current AMD GPU and 
 back on the device of ``parameters``.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import native
 
@@ -74,6 +75,7 @@ class _PureProperty(torch.autograd.Function):
         return value.to(out_device), nans
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_value, _g_nans):
         comp = ctx.comp
         g = g_value.to(comp.device).contiguous()
@@ -114,6 +116,7 @@ class _PureDerivatives(torch.autograd.Function):
         return a.to(out), p.to(out), dp.to(out)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_a, g_p, g_dp):
         par, T, rho = ctx.saved_tensors
         if g_a is None and g_p is None and g_dp is None:

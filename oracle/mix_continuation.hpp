@@ -13,7 +13,8 @@
 //     unknown densities, step halving on any failure);
 //   * the start point comes from a fully BRACKETED pure-fluid solve along the composition line (spinodals by scanning,
 //     Maxwell construction by bisection in ln p) -- no Newton from a guess;
-//   * both ends are tried (from component 1 and from component 2); the curve may end before the target in a critical
+//   * both ends are followed (from component 1 and from component 2) and, where they arrive at different solutions, the stable
+//     one is returned (dew: lower pressure, bubble: higher); the curve may end before the target in a critical
 //     point (phases become identical) or a liquid-liquid region (the liquid phase becomes mechanically or diffusionally
 //     unstable), which is reported.
 //
@@ -179,7 +180,8 @@ int corrector(const Model& model, F T, const F* z, F& rs, F* ri, F tol, F cap, i
 template <class F, class Model>
 ContInfo bubble_dew_continuation(const Model& model, F T, F z1, bool dew, F* rho_spec, F* rho_inc, F tol = F(1e-12)) {
     using namespace cont_detail;
-    ContInfo best;
+    ContInfo best, found;
+    F p_found = F(0);
     const F xi_target = log(z1 / (F(1) - z1));
     bool any_start = false, any_critical = false;
     for (int route = 0; route < 2; route++) {
@@ -276,16 +278,27 @@ ContInfo bubble_dew_continuation(const Model& model, F T, F z1, bool dew, F* rho
                 F dens_i = ri[0] + ri[1];
                 F lo = dew ? rs : dens_i, hi = dew ? dens_i : rs;
                 if (lo < hi * (F(1) - F(1e-6))) {
-                    rho_spec[0] = z[0] * rs; rho_spec[1] = z[1] * rs;
-                    rho_inc[0] = ri[0]; rho_inc[1] = ri[1];
-                    info.code = CONT_OK;
-                    return info;
+                    // a solution at the target.  BOTH routes are followed: where they arrive at different solutions (a
+                    // liquid-liquid split: two incipient liquids satisfy the dew equations, two vapours never do) the
+                    // STABLE one is kept -- at fixed vapour composition the dew point is the lowest pressure at which a liquid
+                    // can form, at fixed liquid composition the bubble point the highest at which a vapour can
+                    F r_s[2] = {z[0] * rs, z[1] * rs};
+                    const F p_here = eval_phase<F>(model, T, r_s).p();
+                    if (found.code != CONT_OK || (dew ? p_here < p_found : p_here > p_found)) {
+                        rho_spec[0] = r_s[0]; rho_spec[1] = r_s[1];
+                        rho_inc[0] = ri[0]; rho_inc[1] = ri[1];
+                        info.code = CONT_OK;
+                        found = info;
+                        p_found = p_here;
+                    }
+                    continue;
                 }
             }
         }
         any_critical = any_critical || critical;
         if (info.steps > best.steps) { best.steps = info.steps; best.newton = info.newton; best.route = route; }
     }
+    if (found.code == CONT_OK) return found;
     best.code = !any_start ? CONT_NO_START : (any_critical ? CONT_CRITICAL : CONT_STALLED);
     return best;
 }

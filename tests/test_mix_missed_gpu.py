@@ -41,8 +41,12 @@ def test_failed_rows_have_no_reachable_solution(oracle, dew):
           f"critical end {(code == 2).sum()}, stalled {(code == 3).sum()}, no pure-fluid VLE {(code == 1).sum()}")
     assert len(idx) <= MAX_FAILED[dew]
     assert missed <= MAX_MISSED[dew]
-    # and on a sample of the rows the kernel DOES solve, the independent solver lands on the same pressure unless the row has
-    # more than one solution (liquid-liquid split: two incipient liquids satisfy the dew equations)
+    # and on a sample of the rows the kernel DOES solve, the independent solver lands on the same pressure.  Rows with more than
+    # one solution (liquid-liquid split: two incipient liquids satisfy the dew equations; 1.7 % of the dew rows) are judged by
+    # stability: the continuation follows the curve from BOTH pure-component ends and keeps the stable arrival -- at fixed vapour
+    # composition the dew point is the LOWEST pressure at which a liquid can form, at fixed liquid composition the bubble point
+    # the HIGHEST at which a vapour can (oracle/mix_continuation.hpp).  Round 3, CPU restatement, 3,031 dew rows: the same
+    # solution on 99.5 %; of the 15 others the kernel's is the more stable one on 9 (a third solution neither route passes).
     ok = np.nonzero(~failed)[0][:: max(1, N // 3000)]
     pC, rC, code, info = oracle.mix_bubble_dew_continuation(P[ok], K[ok], T[ok], X[ok], dew, prec=0)
     got = r["p"].cpu().numpy()[ok]
@@ -52,16 +56,11 @@ def test_failed_rows_have_no_reachable_solution(oracle, dew):
     print(f"   sample of {len(ok)} solved rows: continuation solves {both.sum()}, same solution on {same.sum()}, another solution on {(~same).sum()}, "
           f"max rel among the same {rel[same].max():.2e}")
     assert both.mean() > 0.9
-    assert same.mean() > (0.95 if dew else 0.99)
+    assert same.mean() >= 0.99
     assert rel[same].max() < 1e-8
-    # ... and where the two solvers land on DIFFERENT solutions, the kernel's is the stable one: at fixed vapour composition
-    # the dew point is the LOWEST pressure at which a liquid can form (above it the vapour would already have condensed), at
-    # fixed liquid composition the bubble point is the HIGHEST pressure at which a vapour can form.  Round 3, 12,000 rows on
-    # the CPU restatement: 191 of 198 differing dew rows and 19 of 21 differing bubble rows on the stable side -- the
-    # continuation solver, which follows one branch from a pure-component end, is the one that lands on the metastable root.
     stable_side = (got[both] < pC[both]) if dew else (got[both] > pC[both])
     ok_root = same | stable_side
-    print(f"   of the {(~same).sum()} rows with another solution the kernel's is the stable one on {(~same & stable_side).sum()}")
+    print(f"   of the {(~same).sum()} rows with another solution the kernel's is the more stable one on {(~same & stable_side).sum()}")
     assert ok_root.mean() >= 0.995
 
 

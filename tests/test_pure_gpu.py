@@ -436,3 +436,20 @@ def test_hipgraph_replay_behind_pending_work_equals_eager(amd):
         torch.cuda.synchronize()
         for got, want in zip((plan.p_sat, plan.rho_eq, plan.rho_vl, plan.status), ref):
             assert torch.equal(got, want), rep
+
+
+def test_second_derivatives_are_refused_not_silently_wrong(amd):
+    """The property Functions deliver first derivatives from the Jacobian kernels; a second differentiation
+    (`create_graph=True` + another backward: the reference's plain-torch tails allow it, no reference test uses it) has no
+    kernel behind it and must raise instead of returning a gradient without the second-order terms."""
+    from feos_torch_amd import PcSaftPure
+    from feos_torch_amd.synthetic import pure_batch
+
+    P, T = pure_batch(64, seed=5)
+    par = torch.from_numpy(P).cuda().requires_grad_(True)
+    _, p = PcSaftPure(par).vapor_pressure(torch.from_numpy(T).cuda())
+    (g,) = torch.autograd.grad(p.sum(), par, create_graph=True)
+    # (the backward passes are marked once_differentiable: the gradient carries no graph, so a second backward raises)
+    assert not g.requires_grad
+    with pytest.raises(RuntimeError, match="once_differentiable|differentiate twice|does not require grad"):
+        g.sum().backward()
