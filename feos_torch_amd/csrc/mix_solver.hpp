@@ -88,18 +88,19 @@ PCS_DEV bool solve3(double A[3][4], double* x) {
     if (fabs(A[1][0]) > fabs(A[0][0])) swap_rows(A[0], A[1]);
     if (fabs(A[2][0]) > fabs(A[0][0])) swap_rows(A[0], A[2]);
     if (A[0][0] == 0.0) return false;
-    double inv = 1.0 / A[0][0];
+    double inv = d_recip(A[0][0]);
     double f1 = A[1][0] * inv, f2 = A[2][0] * inv;
 #pragma unroll
     for (int j = 1; j < 4; j++) { A[1][j] -= f1 * A[0][j]; A[2][j] -= f2 * A[0][j]; }
     if (fabs(A[2][1]) > fabs(A[1][1])) swap_rows(A[1], A[2]);
     if (A[1][1] == 0.0) return false;
-    double f = A[2][1] / A[1][1];
+    const double inv1 = d_recip(A[1][1]);
+    double f = A[2][1] * inv1;
     A[2][2] -= f * A[1][2];
     A[2][3] -= f * A[1][3];
     if (A[2][2] == 0.0) return false;
-    x[2] = A[2][3] / A[2][2];
-    x[1] = (A[1][3] - A[1][2] * x[2]) / A[1][1];
+    x[2] = A[2][3] * d_recip(A[2][2]);
+    x[1] = (A[1][3] - A[1][2] * x[2]) * inv1;
     x[0] = (A[0][3] - A[0][1] * x[1] - A[0][2] * x[2]) * inv;
     return true;
 }

@@ -236,8 +236,8 @@ struct BdLane {
                 }
                 if (!bad) {  // phase 2: bracket update, scaled Newton, bisection where Newton leaves the bracket
                     if (above) r_hi = r_rho; else r_lo = r_rho;
-                    const double den = dp - 4.0 * (p - r_pspec) * r_pk / (1.0 - r_rho * r_pk);
-                    rho_new = (dp > 0.0 && den > 0.0) ? r_rho - (p - r_pspec) / den : -1.0;
+                    const double den = dp - 4.0 * (p - r_pspec) * r_pk * d_recip(1.0 - r_rho * r_pk);
+                    rho_new = (dp > 0.0 && den > 0.0) ? r_rho - (p - r_pspec) * d_recip(den) : -1.0;
                     const bool newton = rho_new > r_lo && rho_new < r_hi;
                     if (!newton) rho_new = 0.5 * (r_lo + r_hi);
                     step = r_rho - rho_new;
@@ -251,9 +251,9 @@ struct BdLane {
                 r_dense = true;
                 return;
             }
-            double den = r_dense ? dp : dp - 4.0 * (p - r_pspec) * r_pk / (1.0 - r_rho * r_pk);
+            double den = r_dense ? dp : dp - 4.0 * (p - r_pspec) * r_pk * d_recip(1.0 - r_rho * r_pk);
             bad = !(dp > 0.0) || !(den > 0.0) || !is_finite_bits(p);
-            step = (p - r_pspec) / den;
+            step = (p - r_pspec) * d_recip(den);
             rho_new = r_rho - step;
             bad = bad || !(rho_new > 0.0) || !is_finite_bits(rho_new);
             // dense restart: the root is bracketed by eta = 0.5 (p < p_spec) and 0.62 (p > p_spec).  An iterate that leaves
@@ -262,7 +262,7 @@ struct BdLane {
             // systematic search always takes the first bracket above eta = 0.5
             bad = bad || (r_dense && !(rho_new * r_pk > 0.5 && rho_new * r_pk < 0.62));
             if (!bad) {
-                double err = fabs(step) / r_rho;
+                double err = fabs(step) * d_recip(r_rho);
                 done = err <= LIQ_ROOT_TOL || (r_it >= 3 && err < 1e-7 && err >= 0.25 * r_errprev);
                 r_errprev = err;
                 r_it++;
@@ -323,7 +323,7 @@ struct BdLane {
 
         if (stage == S_SS) {
             double p = e.p(), dp = x0 * e.dp0() + x1 * e.dp1();
-            double drho = -p / dp;
+            double drho = -p * d_recip(dp);
             const bool fine = (dp > 0.0) && is_finite_bits(p);
             if (!(fine && fabs(drho) <= 0.05 * rl)) {
                 if (!resolved) {  // composition moved a lot: re-solve the liquid root here, then redo the sweep
@@ -342,22 +342,23 @@ struct BdLane {
             const double Gm = fmin(G0, G1);
             const double w0 = z0 * exp(Gm - G0), w1 = z1 * exp(Gm - G1);
             rl = rlc;
-            const double sum = (w0 + w1) / (rlc * exp(Gm));
-            double n0 = w0 / (w0 + w1), n1 = w1 / (w0 + w1);
+            const double rw = d_recip(w0 + w1);
+            const double sum = (w0 + w1) * d_recip(rlc * exp(Gm));
+            double n0 = w0 * rw, n1 = w1 * rw;
             const double dx = fabs(n0 - x0);
-            const double xi = d_log(x0 / x1);
-            const double res = d_log(n0 / n1) - xi;
+            const double xi = d_log(x0 * d_recip(x1));
+            const double res = d_log(n0 * d_recip(n1)) - xi;
             bool secant = false;
             // bracket of the fixed point: r > 0 at xi_lo, r < 0 at xi_hi (see mix_solver.hpp)
             if (res > 0.0 && xi > xi_lo) xi_lo = xi;
             if (res < 0.0 && xi < xi_hi) xi_hi = xi;
             if (ss > 0 && xi != xi_prev) {
-                const double slope = (res - res_prev) / (xi - xi_prev);
+                const double slope = (res - res_prev) * d_recip(xi - xi_prev);
                 if (slope < SS_SECANT_SLOPE) {
-                    const double dxi = fmin(fmax(-res / slope, -1.6), 1.6);
+                    const double dxi = fmin(fmax(-res * d_recip(slope), -1.6), 1.6);
                     const double ee = exp(xi + dxi);
-                    x0 = ee / (1.0 + ee);
-                    x1 = 1.0 / (1.0 + ee);
+                    x1 = d_recip(1.0 + ee);
+                    x0 = ee * x1;
                     secant = true;
                 }
             }
@@ -367,20 +368,21 @@ struct BdLane {
                 n0 = fmin(fmax(n0, 0.2 * x0), 5.0 * x0);
                 n1 = fmin(fmax(n1, 0.2 * x1), 5.0 * x1);
                 const double s2 = n0 + n1;
-                x0 = n0 / s2;
-                x1 = n1 / s2;
+                const double rs2 = d_recip(s2);
+                x0 = n0 * rs2;
+                x1 = n1 * rs2;
             }
             bool narrow = false;
             if (xi_lo < xi_hi && xi_lo > -1e299 && xi_hi < 1e299) {
-                const double xin = d_log(x0 / x1);
+                const double xin = d_log(x0 * d_recip(x1));
                 if (!(xin > xi_lo && xin < xi_hi)) {
                     const double ee = exp(0.5 * (xi_lo + xi_hi));
-                    x0 = ee / (1.0 + ee);
-                    x1 = 1.0 / (1.0 + ee);
+                    x1 = d_recip(1.0 + ee);
+                    x0 = ee * x1;
                 }
                 narrow = xi_hi - xi_lo < SS_TOL;
             }
-            p0 = 1.0 / sum;
+            p0 = d_recip(sum);
             ss++;
             const bool settled = (dx < SS_TOL && fabs(res) < SS_RES_TOL) || narrow;
             if (settled || ss >= ss_max) {
@@ -405,14 +407,14 @@ struct BdLane {
             const PhaseEval& s = sv;
             const PhaseEval& n = e;
             double A[3][4];
-            A[0][0] = rs * (z0 * (1.0 / s.r0 + s.h00) + z1 * s.h01);
-            A[1][0] = rs * (z0 * s.h01 + z1 * (1.0 / s.r1 + s.h11));
+            A[0][0] = rs * (z0 * (d_recip(s.r0) + s.h00) + z1 * s.h01);
+            A[1][0] = rs * (z0 * s.h01 + z1 * (d_recip(s.r1) + s.h11));
             A[2][0] = rs * (z0 * s.dp0() + z1 * s.dp1());
-            A[0][1] = -ri0 * (1.0 / ri0 + n.h00);
+            A[0][1] = -(1.0 + ri0 * n.h00);
             A[1][1] = -ri0 * n.h01;
             A[2][1] = -ri0 * n.dp0();
             A[0][2] = -ri1 * n.h01;
-            A[1][2] = -ri1 * (1.0 / ri1 + n.h11);
+            A[1][2] = -(1.0 + ri1 * n.h11);
             A[2][2] = -ri1 * n.dp1();
             A[0][3] = -(s.mu0() - n.mu0());
             A[1][3] = -(s.mu1() - n.mu1());
@@ -442,7 +444,7 @@ struct BdLane {
             const double rtot = ri0 + ri1;
             const bool tr0 = ri0 < NEWTON_TRACE * rtot, tr1 = ri1 < NEWTON_TRACE * rtot;
             const double mxl = fmax(fabs(du[0]), fmax(tr0 ? 0.0 : fabs(du[1]), tr1 ? 0.0 : fabs(du[2])));
-            const double scale = mxl > 1.0 ? 1.0 / mxl : 1.0;
+            const double scale = mxl > 1.0 ? d_recip(mxl) : 1.0;
             st0 = scale * du[0];
             st1 = tr0 ? fmin(fmax(du[1], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[1];
             st2 = tr1 ? fmin(fmax(du[2], -NEWTON_TRACE_MAX), NEWTON_TRACE_MAX) : scale * du[2];
