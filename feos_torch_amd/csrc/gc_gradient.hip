@@ -38,6 +38,9 @@ constexpr int GS_GRID = 2048;
 // dual-number directions per pass.  MODE 0 (D1 probes): one molecule-level quantity of BOTH molecules (slot j = molecule j);
 // MODE 1 (T2 probes, three times the state per value): one molecule per pass -- with two the stack frame is 4.4 KB per lane
 template <int MODE> struct GsChunk { static constexpr int value = MODE == 0 ? 2 : 1; };
+// LDS doubles per thread behind the table and the gradient accumulator: the double model's bond list (4 * MAXE) + the dual model's
+// bond diameters, which double as the lane-strided coefficient-adjoint array of MODE 0 (ADJ_SLOTS); the row bytes follow (stage_row)
+constexpr int GS_PER_THREAD = 4 * GC_MAXE + (2 * GC_MAXE * (1 + 2) > ADJ_SLOTS ? 2 * GC_MAXE * (1 + 2) : ADJ_SLOTS);
 
 enum : int { Q_M, Q_Z1, Q_Z2, Q_Z3, Q_S3, Q_EK, Q_MU, Q_SA, Q_EA, Q_KA, Q_EAB, Q_NA, Q_NB, Q_COUNT };
 
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
     double* acc = lds + gc_table_doubles(S);                          // [S][8] gradient of this workgroup
     double* bonds = acc + S * 8;                                      // double model: [2*MAXE dab][2*MAXE cnt] x block
     G* gbonds = reinterpret_cast<G*>(bonds + 4 * GC_MAXE * GSBLOCK);  // dual model dab (zero tangents)
+    double* row_area = bonds + GS_PER_THREAD * GSBLOCK;               // the lanes' row bytes (stage_row)
     for (int k = threadIdx.x; k < S * 8; k += GSBLOCK) acc[k] = 0.0;
     __syncthreads();
 
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
             i = order[i];
             if (i < 0 || i >= n) { live = false; i = 0; }
         }
-        const unsigned char* row = rows + (size_t)i * GC_ROW_BYTES;
+        const unsigned char* row = stage_row(rows + (size_t)i * GC_ROW_BYTES, row_area);  // read byte by byte in the loops below
         const double T = temp[i], ph0 = phi[2 * i], ph1 = phi[2 * i + 1];
         const double rT = 1.0 / T;
         // density points of the functional: pt 0 = specified phase (MODE 0) or the state point (MODE 1), pt 1 = incipient phase
@@ -654,9 +658,7 @@ static int launch_gc_gradient(int mode, const GcGradArgs& a, void* stream, const
     const int64_t tiles = (a.n + GSBLOCK - 1) / GSBLOCK;
     const unsigned grid = (unsigned)(tiles < GS_GRID ? tiles : GS_GRID);
     // table + gradient accumulator + per thread: double model 4*MAXE doubles, dual model dab 2*MAXE*(1+CHUNK)
-    // (the dual-model area doubles as the lane-strided coefficient-adjoint array of MODE 0: ADJ_SLOTS doubles per thread)
-    constexpr int per_thread = 4 * GC_MAXE + (2 * GC_MAXE * (1 + 2) > ADJ_SLOTS ? 2 * GC_MAXE * (1 + 2) : ADJ_SLOTS);
-    const size_t lds = gc_lds_bytes(a.S, GSBLOCK, per_thread) + sizeof(double) * a.S * 8;
+    const size_t lds = gc_lds_bytes(a.S, GSBLOCK, GS_PER_THREAD + GC_ROW_LDS_DOUBLES) + sizeof(double) * a.S * 8;
     if (lds > 64 * 1024) {  // large segment tables: above the default dynamic-LDS limit (the CU has 160 KB)
         const void* fn = mode == 0 ? reinterpret_cast<const void*>(k_gc_segment_gradient<0>) : reinterpret_cast<const void*>(k_gc_segment_gradient<1>);
         hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -676,6 +678,7 @@ int pcs_gc_segment_gradient(int dew, const double* table, int S, const uint8_t* 
     if (int e = gc_check(S, n)) return e;
     if (n == 0) return 0;
     if (!table || !rows || !phi || !temp || !rho4 || !grad_seg) return fail_msg("pcs_gc_segment_gradient: null required pointer");
+    if (reinterpret_cast<uintptr_t>(rows) & 15) return fail_msg("pcs_gc_segment_gradient: rows must be 16-byte aligned");
     GcGradArgs a{};
     a.dew = dew; a.table = table; a.S = S; a.rows = rows; a.phi = phi; a.temp = temp; a.rho = rho4; a.n = n;
     a.gout = gout; a.grad_seg = grad_seg; a.order = order;
@@ -689,6 +692,7 @@ int pcs_gc_derivatives_vjp(const double* table, int S, const uint8_t* rows, cons
     if (int e = gc_check(S, n)) return e;
     if (n == 0) return 0;
     if (!table || !rows || !phi || !temp || !rho || !grad_seg || !jac9) return fail_msg("pcs_gc_derivatives_vjp: null required pointer");
+    if (reinterpret_cast<uintptr_t>(rows) & 15) return fail_msg("pcs_gc_derivatives_vjp: rows must be 16-byte aligned");
     GcGradArgs a{};
     a.table = table; a.S = S; a.rows = rows; a.phi = phi; a.temp = temp; a.rho = rho; a.n = n;
     a.g_a = g_a; a.g_p = g_p; a.g_mu = g_mu; a.g_v = g_v; a.grad_seg = grad_seg; a.jac9 = jac9; a.agg = agg; a.order = order;

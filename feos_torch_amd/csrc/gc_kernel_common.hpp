@@ -33,6 +33,24 @@ __device__ __forceinline__ GcTable stage_table(const double* __restrict__ table,
     return tb;
 }
 
+// The 80 structure bytes of this lane's row, staged in LDS.  The model set-up (gc_mol) reads single bytes of the row inside its
+// loops -- 32 for the molecule sums, up to 2 x 192 in the dispersion double sums, 48 for the bonds -- and as global byte loads
+// each of them waits for its own round trip to the cache (one wave per SIMD: nothing hides it).  Lane stride 84 B = 21 dwords
+// (odd: conflict-free for equal offsets); the area is lane-private, no barrier needed.  `area` = GC_ROW_LDS_DOUBLES doubles per
+// thread of the workgroup.
+constexpr int GC_ROW_LDS_STRIDE = 84;
+constexpr int GC_ROW_LDS_DOUBLES = 11;
+__device__ __forceinline__ const unsigned char* stage_row(const unsigned char* __restrict__ row, double* area) {
+    unsigned int* dst = reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(area) + threadIdx.x * GC_ROW_LDS_STRIDE);
+    const uint4* src = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+    for (int k = 0; k < GC_ROW_BYTES / 16; k++) {
+        const uint4 v = src[k];
+        dst[4 * k] = v.x; dst[4 * k + 1] = v.y; dst[4 * k + 2] = v.z; dst[4 * k + 3] = v.w;
+    }
+    return reinterpret_cast<const unsigned char*>(dst);
+}
+
 // the one dual-number evaluation site of the gradient kernels, not inlined (register pressure, see mix_jacobian.hpp)
 template <class G, class R>
 __device__ __attribute__((noinline)) R gc_a_tangent(const GcCoef<G>& c, const R& r0, const R& r1) {

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
     if (RETRY && (int64_t)blockIdx.x * GBLOCK >= (int64_t)retry[0]) return;  // whole workgroup idle: skip the staging
     GcTable tb = stage_table(table, S, lds);
     double* bonds = lds + gc_table_doubles(S);  // [2][16][GBLOCK]: dab then cnt
+    double* row_area = bonds + 4 * GC_MAXE * GBLOCK;  // the lanes' row bytes (stage_row)
     GcModelT<double> m;
     m.c.bond_dab = bonds + threadIdx.x;
     m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
         const int64_t i = RETRY ? (int64_t)retry[1 + k] : k;
         if (RETRY && (i < 0 || i >= n)) continue;
         const double T = temp[i];
-        gc_coef<double>(m.c, rows + (size_t)i * GC_ROW_BYTES, tb, phi[2 * i], phi[2 * i + 1], T);
+        gc_coef<double>(m.c, stage_row(rows + (size_t)i * GC_ROW_BYTES, row_area), tb, phi[2 * i], phi[2 * i + 1], T);
         MixResult r;
         const double p_red = p_init[i] / (T * P_UNIT);
         const bool fast = !RETRY && retry;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_derivatives(const double* __restr
     m.c.bond_dab = bonds + threadIdx.x;
     m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
     m.c.stride = GBLOCK;
-    gc_coef<double>(m.c, rows + (size_t)i * GC_ROW_BYTES, tb, phi[2 * i], phi[2 * i + 1], temp[i]);
+    gc_coef<double>(m.c, stage_row(rows + (size_t)i * GC_ROW_BYTES, bonds + 4 * GC_MAXE * GBLOCK), tb, phi[2 * i], phi[2 * i + 1], temp[i]);
     PhaseEval e = phase_eval(m, rho[2 * i], rho[2 * i + 1]);
     if (a) a[i] = e.a;
     if (p) p[i] = e.p();
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* 
         i = order[i];
         if (i < 0 || i >= n) return;
     }
-    const unsigned char* row = rows + (size_t)i * GC_ROW_BYTES;
+    // (row bytes staged behind the dual model's bond area)
+    const unsigned char* row = stage_row(rows + (size_t)i * GC_ROW_BYTES, bonds + (4 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK)) * GJBLOCK);
     const double T = temp[i], ph0 = phi[2 * i], ph1 = phi[2 * i + 1];
     const double4 r4 = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
     const double s0 = dew ? r4.x : r4.z, s1 = dew ? r4.y : r4.w, i0 = dew ? r4.z : r4.x, i1 = dew ? r4.w : r4.y;
@@ -325,8 +327,9 @@ int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, 
     if (int e = gc_check(S, n)) return e;
     if (n == 0) return 0;
     if (!table || !rows || !phi || !temp || !z || !p_init || !status) return fail_msg("pcs_gc_bubble_dew: null required pointer");
+    if (reinterpret_cast<uintptr_t>(rows) & 15) return fail_msg("pcs_gc_bubble_dew: rows must be 16-byte aligned");
     const unsigned grid = (unsigned)((n + GBLOCK - 1) / GBLOCK);
-    const size_t lds = gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE);
+    const size_t lds = gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE + GC_ROW_LDS_DOUBLES);
     hipStream_t s = as_stream(stream);
     int32_t* retry = static_cast<int32_t*>(workspace);
     if (retry) {
@@ -356,8 +359,9 @@ int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const do
     if (int e = gc_check(S, n)) return e;
     if (n == 0) return 0;
     if (!table || !rows || !phi || !temp || !rho) return fail_msg("pcs_gc_derivatives: null required pointer");
+    if (reinterpret_cast<uintptr_t>(rows) & 15) return fail_msg("pcs_gc_derivatives: rows must be 16-byte aligned");
     const unsigned grid = (unsigned)((n + GBLOCK - 1) / GBLOCK);
-    hipLaunchKernelGGL(k_gc_derivatives, dim3(grid), dim3(GBLOCK), gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE), as_stream(stream),
+    hipLaunchKernelGGL(k_gc_derivatives, dim3(grid), dim3(GBLOCK), gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE + GC_ROW_LDS_DOUBLES), as_stream(stream),
                        table, S, rows, phi, temp, rho, n, a, p, mu, v);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_gc_derivatives launch", e);
@@ -370,9 +374,10 @@ int pcs_gc_jacobian(int dew, const double* table, int S, const uint8_t* rows, co
     if (int e = gc_check(S, n)) return e;
     if (n == 0) return 0;
     if (!table || !rows || !phi || !temp || !rho4 || !jac) return fail_msg("pcs_gc_jacobian: null required pointer");
+    if (reinterpret_cast<uintptr_t>(rows) & 15) return fail_msg("pcs_gc_jacobian: rows must be 16-byte aligned");
     const unsigned grid = (unsigned)((n + GJBLOCK - 1) / GJBLOCK);
     // double model: 4*MAXE doubles per thread; dual model dab: 2*MAXE * (1 + GC_CHUNK) doubles per thread
-    const size_t lds = gc_lds_bytes(S, GJBLOCK, 4 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK));
+    const size_t lds = gc_lds_bytes(S, GJBLOCK, 4 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK) + GC_ROW_LDS_DOUBLES);
     hipLaunchKernelGGL(k_gc_jacobian, dim3(grid), dim3(GJBLOCK), lds, as_stream(stream), dew, table, S, rows, phi, temp,
                        rho4, n, jac, agg, order);
     hipError_t e = hipGetLastError();

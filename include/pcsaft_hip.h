@@ -204,7 +204,8 @@ int pcs_mix_jacobian(int dew, const double* params, const double* kij, const dou
  *   table  [S*8 + 3*S*S] in   per-batch: seg[S][8] (m, sigma, epsilon_k, mu, kappa_ab, epsilon_k_ab,
  *                             na, nb), E1[S][S] = sqrt(eps_a eps_b) sigma_ab^3, E2[S][S] = eps_a eps_b
  *                             sigma_ab^3, K[S][S] = 1 - k_ab, sigma_ab = (sigma_a + sigma_b)/2; S <= 32
- *   rows   [n,80] uint8  in   molecule structures: for each of the 2 molecules up to 8 entries of
+ *   rows   [n,80] uint8  in   (16-byte aligned: the kernels take a row with five 16-byte loads)
+ *                             molecule structures: for each of the 2 molecules up to 8 entries of
  *                             seg_id [0:16], seg_cnt [16:32], bond_a [32:48], bond_b [48:64],
  *                             bond_cnt [64:80] (count 0 = unused entry)
  *   phi    [n,2]         in   src/gc_pcsaft.rs:30, feos_torch/gc_pcsaft.py:182-185
