@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64, 1) void k_mix_init_queue(const double* __restri
         if (!L.done()) {
             double e0, e1;
             L.point(e0, e1);
-            PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
+            PhaseEval e = phase_eval_inline(m, e0, e1);  // the only evaluation site of the kernel, inlined (see mix_solver.hpp)
             L.consume(m, e);
             if (++evals >= BD_EVAL_GUARD && !L.done()) L.idle();  // rc = BD_FAILED
             if (L.done()) {
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64, 1) void k_mix_bubble_dew_queue(const double* __
         if (!L.done()) {
             double e0, e1;
             L.point(e0, e1);
-            PhaseEval e = phase_eval(m, e0, e1);  // the only evaluation site
+            PhaseEval e = phase_eval_inline(m, e0, e1);  // the only evaluation site of the kernel, inlined (see mix_solver.hpp)
             L.consume(m, e);
             // evaluation budget: BD_EVAL_GUARD bounds the plain form, robust_eval_budget the second attempt (mix_solver_sm.hpp)
             if (++evals >= (L.robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD) && !L.done()) L.idle();  // rc = BD_FAILED

@@ -35,9 +35,13 @@ struct PhaseEval {
     PCS_DEV double dp1() const { return 1.0 + r0 * h01 + r1 * h11; }
 };
 
-// The two evaluation entry points are NOT inlined: the solver calls them from ~10 sites, and inlined the
-// kernels spill ~2,700 VGPRs (3.4 KB scratch per lane); as calls 300 (A/B: dew 110 -> 76 ms, bubble 23 -> 18.5 ms
-// per 1e6 rows).
+// The evaluation entry points phase_eval / line_eval are NOT inlined: round 1's sequential solver called them from ~10 sites,
+// and inlined the kernels spilled ~2,700 VGPRs (3.4 KB scratch per lane); as calls 300 (A/B: dew 110 -> 76 ms, bubble 23 ->
+// 18.5 ms per 1e6 rows).  The two work-queue kernels of mix_kernels.hip -- ONE evaluation site each, solver state in LDS -- call
+// phase_eval_inline since round 3: the model coefficients then stay in registers / AGPRs instead of being read back from the
+// caller's stack frame by ~37 loads per evaluation (512 -> 104-160 B of scratch): bubble 2.34 -> 2.20 ms, dew 4.94 -> 4.61 ms
+// per 1e6 rows, results within 5e-13.  (The gc solver kernel, whose state machine is instantiated for two attempts and keeps its
+// state in registers, gets slower inlined: dew 3.66 -> 4.2 ms.)
 #ifndef PCS_EVAL_ATTR
 #define PCS_EVAL_ATTR __device__ __attribute__((noinline))
 #endif
