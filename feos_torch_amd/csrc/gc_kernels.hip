@@ -140,13 +140,20 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
         // evaluations otherwise; round 3: dew 4.25 -> 4.02 ms per 1e6 rows)
         double fug[2], rho_pure[2];
         if (DEW) pure_fugacities_on_the_line(m, fug, rho_pure);
-        int rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT, false, &root_failed,
-                                          DEW ? fug : nullptr, DEW ? rho_pure : nullptr, false);
         // (may_damp = false: no damped second run of a failed Newton here -- mix_solver_sm.hpp::newton_failed.  The second pass
         // ends with its slowest row, and on the synthetic batch the damped run recovers 1 row per 1e6 for +0.2 ms.)
-        // a row that fails at a liquid root with the full caps gets the robust second attempt (bracketed liquid roots,
-        // mix_solver_sm.hpp): in the second pass, or in place when there is no work list
-        if (!fast && rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
+        // A row that fails at a liquid root with the full caps gets the robust second attempt (bracketed liquid roots,
+        // mix_solver_sm.hpp): in the second pass, or in place when there is no work list.
+        int rc;
+        if constexpr (DEW) {
+            rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT, false,
+                                          &root_failed, fug, rho_pure, false);
+            if (!fast && rc != BD_OK && root_failed) rc = bubble_dew_solve_sm<DEW>(m, z[i], p_red, r, SS_MAX_IT, NEWTON_MAX_IT, true);
+        } else {
+            (void)root_failed;
+            rc = bubble_dew_solve_sm_both<DEW>(m, z[i], p_red, r, fast ? GC_FAST_SS : SS_MAX_IT, fast ? GC_FAST_NEWTON : NEWTON_MAX_IT, !fast,
+                                               nullptr, nullptr, false);
+        }
         if (fast && rc != BD_OK) {  // cap hit or failed: the second pass decides
             status[i] = 1;  // provisional
             const int slot = atomicAdd(&retry[0], 1);

@@ -565,4 +565,36 @@ PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixRes
     return L.done() ? L.rc : BD_FAILED;
 }
 
+// The same with ONE loop and one INLINED evaluation site for both attempts: the plain form and -- `second_attempt`, only if one
+// of its liquid roots failed -- the robust form, restarted in place on the lanes that need it while the others idle (as the
+// work-queue kernels do).  Used by the gc bubble-point kernel (1.48 -> 1.43 ms per 1e6 rows); the gc dew-point kernel, which also
+// carries the one-variable evaluation of the pure-liquid fugacities, is faster with the two calls above (3.63 vs 3.73 ms, and 4.0
+// with the evaluation inlined).
+template <bool DEW, class Model>
+PCS_DEV int bubble_dew_solve_sm_both(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
+                                int newton_max = NEWTON_MAX_IT, bool second_attempt = true, const double* fug = nullptr,
+                                const double* rho_pure = nullptr, bool may_damp = true) {
+    BdLane<DEW> L;
+    if (fug) L.start(m, z0, p_init, ss_max, newton_max, false, fug[0], fug[1], rho_pure[0], rho_pure[1]);
+    else L.start(m, z0, p_init, ss_max, newton_max, false);
+    L.may_damp = may_damp;
+    int evals = 0;
+    for (int guard = 0; guard < BD_EVAL_GUARD + robust_eval_budget<DEW>(); guard++) {
+        if (__ballot(!L.done()) == 0ull) break;
+        if (L.done()) continue;
+        double e0, e1;
+        L.point(e0, e1);
+        PhaseEval e = phase_eval_inline(m, e0, e1);  // the only evaluation site, inlined
+        L.consume(m, e);
+        if (++evals >= (L.robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD) && !L.done()) L.idle();  // rc = BD_FAILED
+        if (second_attempt && L.done() && L.rc != BD_OK && !L.robust && L.root_failed) {
+            L.start(m, z0, p_init, SS_MAX_IT, NEWTON_MAX_IT, true);
+            L.may_damp = may_damp;
+            evals = 0;
+        }
+    }
+    out = L.out;
+    return L.done() ? L.rc : BD_FAILED;
+}
+
 }  // namespace pcs
