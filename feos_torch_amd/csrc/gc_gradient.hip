@@ -40,7 +40,8 @@ constexpr int GS_GRID = 2048;
 template <int MODE> struct GsChunk { static constexpr int value = MODE == 0 ? 2 : 1; };
 // LDS doubles per thread behind the table and the gradient accumulator: the double model's bond list (4 * MAXE) + the dual model's
 // bond diameters, which double as the lane-strided coefficient-adjoint array of MODE 0 (ADJ_SLOTS); the row bytes follow (stage_row)
-constexpr int GS_PER_THREAD = 4 * GC_MAXE + (2 * GC_MAXE * (1 + 2) > ADJ_SLOTS ? 2 * GC_MAXE * (1 + 2) : ADJ_SLOTS);
+// (MODE 0: the coefficient adjoints, the dual model is not instantiated; MODE 1: the dual model with CH = 1 direction)
+template <int MODE> struct GsPerThread { static constexpr int value = 2 * GC_MAXE + (MODE == 0 ? ADJ_SLOTS : 2 * GC_MAXE * (1 + GsChunk<1>::value)); };
 
 enum : int { Q_M, Q_Z1, Q_Z2, Q_Z3, Q_S3, Q_EK, Q_MU, Q_SA, Q_EA, Q_KA, Q_EAB, Q_NA, Q_NB, Q_COUNT };
 
@@ -134,7 +135,7 @@ __device__ __attribute__((noinline)) void gc_a_adjoint(const GcCoef<double>& c, 
 #pragma unroll 1
             for (int e = 0; e < GC_MAXE; e++) {
                 const int slot = (i * GC_MAXE + e) * c.stride;
-                const double n = c.bond_cnt[slot];
+                const double n = (double)c.bond_cnt[i * GC_MAXE + e];
                 if (n == 0.0) continue;
                 const double dab = c.bond_dab[slot];
                 const R cd = cc * dab;
@@ -277,8 +278,9 @@ struct GcGradArgs {
     const int32_t* order;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArgs A_) {
+// BLOCK: 64, or 192 where the LDS of three waves fits one CU next to ONE copy of the table (launch_gc_gradient)
+template <int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_gc_segment_gradient(const GcGradArgs A_) {
     const int dew = A_.dew, S = A_.S;
     const double* __restrict__ table = A_.table;
     const unsigned char* __restrict__ rows = A_.rows;
@@ -296,24 +298,23 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
     extern __shared__ double lds[];
     GcTable tb = stage_table(table, S, lds);
     double* acc = lds + gc_table_doubles(S);                          // [S][8] gradient of this workgroup
-    double* bonds = acc + S * 8;                                      // double model: [2*MAXE dab][2*MAXE cnt] x block
-    G* gbonds = reinterpret_cast<G*>(bonds + 4 * GC_MAXE * GSBLOCK);  // dual model dab (zero tangents)
-    double* row_area = bonds + GS_PER_THREAD * GSBLOCK;               // the lanes' row bytes (stage_row)
-    for (int k = threadIdx.x; k < S * 8; k += GSBLOCK) acc[k] = 0.0;
+    double* bonds = acc + S * 8;                                      // double model: [2*MAXE dab] x block
+    G* gbonds = reinterpret_cast<G*>(bonds + 2 * GC_MAXE * BLOCK);  // dual model dab (zero tangents)
+    double* row_area = bonds + GsPerThread<MODE>::value * BLOCK;     // the lanes' row bytes (stage_row)
+    for (int k = threadIdx.x; k < S * 8; k += BLOCK) acc[k] = 0.0;
     __syncthreads();
 
     GcModelT<double> m;
     m.c.bond_dab = bonds + threadIdx.x;
-    m.c.bond_cnt = bonds + 2 * GC_MAXE * GSBLOCK + threadIdx.x;
-    m.c.stride = GSBLOCK;
+    m.c.stride = BLOCK;
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
 
-    const int64_t tiles = (n + GSBLOCK - 1) / GSBLOCK;
+    const int64_t tiles = (n + BLOCK - 1) / BLOCK;
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         // every lane runs the body (the accumulation below is a wave-level reduction); lanes past the end repeat a valid
         // row with weight zero
-        int64_t i = tile * GSBLOCK + threadIdx.x;
+        int64_t i = tile * BLOCK + threadIdx.x;
         bool live = i < n;
         if (!live) i = n - 1;
         if (order) {
@@ -333,7 +334,8 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
         }
 
         GcMol<double, double> ml;
-        gc_mol<double>(ml, m.c.bond_dab, m.c.bond_cnt, m.c.stride, row, tb, rT);
+        m.c.bond_cnt = row + 64;
+        gc_mol<double>(ml, m.c.bond_dab, m.c.stride, row, tb, rT);
         gc_finish<double, double>(m.c, ml, ph0, ph1, rT);
 
         double alpha[2], beta0[2], beta1[2];
@@ -452,13 +454,13 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
             // coefficient adjoints of both phases (closed form), then their chain to the 26 sums
             double* adj = reinterpret_cast<double*>(gbonds) + threadIdx.x;
 #pragma unroll
-            for (int k = 0; k < ADJ_SLOTS; k++) adj[k * GSBLOCK] = 0.0;
+            for (int k = 0; k < ADJ_SLOTS; k++) adj[k * BLOCK] = 0.0;
 #pragma unroll 1
             for (int pt = 0; pt < 2; pt++)
                 gc_a_adjoint(m.c, pt == 0 ? s0 : i0, pt == 0 ? s1 : i1, pt == 0 ? beta0[0] : beta0[1], pt == 0 ? beta1[0] : beta1[1],
-                             pt == 0 ? alpha[0] : alpha[1], adj, GSBLOCK);
+                             pt == 0 ? alpha[0] : alpha[1], adj, BLOCK);
             double val[Q_COUNT * 2];
-            gc_finish_gradient(ml, m.c.acls, m.c.polar, rT, adj, GSBLOCK, val);
+            gc_finish_gradient(ml, m.c.acls, m.c.polar, rT, adj, BLOCK, val);
             const bool polar = m.c.polar, assoc = m.c.acls != ASSOC_NONE;
 #pragma unroll 1
             for (int q = 0; q < Q_COUNT; q++) {
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
         } else {
             // zero-tangent dual copy of the bond diameters (their derivative is part (3))
 #pragma unroll 1
-            for (int e = 0; e < 2 * GC_MAXE; e++) gbonds[threadIdx.x + e * GSBLOCK] = G(m.c.bond_dab[e * GSBLOCK]);
+            for (int e = 0; e < 2 * GC_MAXE; e++) gbonds[threadIdx.x + e * BLOCK] = G(m.c.bond_dab[e * BLOCK]);
             const bool polar = m.c.polar, assoc = m.c.acls != ASSOC_NONE;
 #pragma unroll 1
             for (int qq = 0; qq < Q_COUNT * (3 - CH); qq++) {
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
                 GcCoef<G> c;
                 c.bond_dab = gbonds + threadIdx.x;
                 c.bond_cnt = m.c.bond_cnt;
-                c.stride = GSBLOCK;
+                c.stride = BLOCK;
                 gc_finish_tangent<G, CH>(c, ml, q, jm, ph0, ph1, rT);
                 double val[2] = {0.0, 0.0};
 #pragma unroll 1
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
             GcCoef<G> c;
             c.bond_dab = gbonds + threadIdx.x;
             c.bond_cnt = m.c.bond_cnt;  // counts are rewritten identically
-            c.stride = GSBLOCK;
+            c.stride = BLOCK;
 #pragma unroll 1
             for (int pass = 0; pass < 3; pass++) {  // T (through the full coefficient set-up), rho_0, rho_1
                 if (pass < 2) {
@@ -616,8 +618,8 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
         for (int mi = 0; mi < 2; mi++) {
 #pragma unroll 1
             for (int e = 0; e < GC_MAXE; e++) {
-                const int slot = (mi * GC_MAXE + e) * GSBLOCK;
-                const double cnt = m.c.bond_cnt[slot];
+                const int slot = (mi * GC_MAXE + e) * BLOCK;
+                const double cnt = (double)m.c.bond_cnt[mi * GC_MAXE + e];
                 const bool on = live && cnt != 0.0;
                 if (__ballot(on) == 0ull) continue;
                 const double dab = m.c.bond_dab[slot];
@@ -644,31 +646,48 @@ __global__ __launch_bounds__(GSBLOCK) void k_gc_segment_gradient(const GcGradArg
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < S * 8; k += GSBLOCK) {
+    for (int k = threadIdx.x; k < S * 8; k += BLOCK) {
         const double v = acc[k];
         if (v != 0.0) unsafeAtomicAdd(grad_seg + k, v);
     }
 }
 
+template <int MODE, int BLOCK>
+static int launch_gc_gradient_block(const GcGradArgs& a, size_t lds, void* stream, const char* what) {
+    const int64_t tiles = (a.n + BLOCK - 1) / BLOCK;
+    const int64_t cap = (int64_t)GS_GRID * GSBLOCK / BLOCK;
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+    if (lds > 64 * 1024) {  // above the default dynamic-LDS limit (the CU has 160 KB)
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gc_segment_gradient<MODE, BLOCK>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return fail(what, ea);
+    }
+    hipLaunchKernelGGL((k_gc_segment_gradient<MODE, BLOCK>), dim3(grid), dim3(BLOCK), lds, as_stream(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(what, e);
+    return 0;
+}
+
+template <int MODE>
+static int launch_gc_gradient_mode(const GcGradArgs& a, void* stream, const char* what) {
+    auto lds_of = [&](int block) { return gc_lds_bytes(a.S, block, GsPerThread<MODE>::value + GC_ROW_LDS_DOUBLES) + sizeof(double) * a.S * 8; };
+    constexpr size_t LDS_CU = 160 * 1024;
+    if (lds_of(256) <= LDS_CU) return launch_gc_gradient_block<MODE, 256>(a, lds_of(256), stream, what);
+    if (lds_of(192) <= LDS_CU) return launch_gc_gradient_block<MODE, 192>(a, lds_of(192), stream, what);
+    return launch_gc_gradient_block<MODE, GSBLOCK>(a, lds_of(GSBLOCK), stream, what);
+}
 }  // namespace
 
 extern "C" {
 
+// LDS of a workgroup: table + gradient accumulator + per thread: bond diameters 2*MAXE doubles, the dual model's diameters
+// 2*MAXE*(1+CHUNK) / the coefficient adjoints, the row bytes.  The kernel holds a full register file per wave and waits mostly
+// for its own stack frame, so the number of resident waves is what counts (measured: one wave per CU 6.6 ms, two 3.8 ms per 1e6
+// rows): 64-thread workgroups carry one copy of the table each and fit twice (S = 22: 59 KB); a 192-thread workgroup shares one
+// copy among three waves (S = 22: 149 KB; the VJP of `derivatives`, MODE 1, needs less per thread: four waves, 132 KB) -- the
+// largest workgroup that fits the CU's 160 KB is taken.
 static int launch_gc_gradient(int mode, const GcGradArgs& a, void* stream, const char* what) {
-    const int64_t tiles = (a.n + GSBLOCK - 1) / GSBLOCK;
-    const unsigned grid = (unsigned)(tiles < GS_GRID ? tiles : GS_GRID);
-    // table + gradient accumulator + per thread: double model 4*MAXE doubles, dual model dab 2*MAXE*(1+CHUNK)
-    const size_t lds = gc_lds_bytes(a.S, GSBLOCK, GS_PER_THREAD + GC_ROW_LDS_DOUBLES) + sizeof(double) * a.S * 8;
-    if (lds > 64 * 1024) {  // large segment tables: above the default dynamic-LDS limit (the CU has 160 KB)
-        const void* fn = mode == 0 ? reinterpret_cast<const void*>(k_gc_segment_gradient<0>) : reinterpret_cast<const void*>(k_gc_segment_gradient<1>);
-        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ea != hipSuccess) return fail(what, ea);
-    }
-    if (mode == 0) hipLaunchKernelGGL(k_gc_segment_gradient<0>, dim3(grid), dim3(GSBLOCK), lds, as_stream(stream), a);
-    else hipLaunchKernelGGL(k_gc_segment_gradient<1>, dim3(grid), dim3(GSBLOCK), lds, as_stream(stream), a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(what, e);
-    return 0;
+    return mode == 0 ? launch_gc_gradient_mode<0>(a, stream, what) : launch_gc_gradient_mode<1>(a, stream, what);
 }
 
 int pcs_gc_segment_gradient(int dew, const double* table, int S, const uint8_t* rows, const double* phi, const double* temp,

@@ -19,7 +19,10 @@ namespace {
 
 constexpr int PCS_GBLOCK = 128;
 constexpr int GBLOCK = PCS_GBLOCK;
-constexpr int GJBLOCK = 64;
+// Jacobian kernel: 59 doubles of LDS per thread (bond diameters of the double and the dual model, row bytes); a 256-thread workgroup
+// shares ONE copy of the table among four waves (S = 22: 131 KB, S = 32: 144 KB of the CU's 160 KB) -- 64-thread workgroups fit three
+// times (one wave each): the kernel holds a full register file per wave, so resident waves per CU are what counts
+constexpr int GJBLOCK = 256;
 
 constexpr int PCS_GC_FAST_SS = 6;  // A/B on the synthetic dew batch (scripts/dev/ab_gc.py): 12/12: 9.0 ms, 6/8: 7.9, 4/8: 8.4, 7/7: 8.6
 constexpr int PCS_GC_FAST_NEWTON = 8;
@@ -86,11 +89,10 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_bubble_dew(const double* __restri
     extern __shared__ double lds[];
     if (RETRY && (int64_t)blockIdx.x * GBLOCK >= (int64_t)retry[0]) return;  // whole workgroup idle: skip the staging
     GcTable tb = stage_table(table, S, lds);
-    double* bonds = lds + gc_table_doubles(S);  // [2][16][GBLOCK]: dab then cnt
-    double* row_area = bonds + 4 * GC_MAXE * GBLOCK;  // the lanes' row bytes (stage_row)
+    double* bonds = lds + gc_table_doubles(S);  // [2*MAXE][GBLOCK]: the bond diameters d_ab
+    double* row_area = bonds + 2 * GC_MAXE * GBLOCK;  // the lanes' row bytes (stage_row)
     GcModelT<double> m;
     m.c.bond_dab = bonds + threadIdx.x;
-    m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
     m.c.stride = GBLOCK;
     int64_t first = (int64_t)blockIdx.x * GBLOCK + threadIdx.x;
     if (!RETRY && order) {
@@ -180,9 +182,8 @@ __global__ __launch_bounds__(GBLOCK) void k_gc_derivatives(const double* __restr
     if (i >= n) return;
     GcModelT<double> m;
     m.c.bond_dab = bonds + threadIdx.x;
-    m.c.bond_cnt = bonds + 2 * GC_MAXE * GBLOCK + threadIdx.x;
     m.c.stride = GBLOCK;
-    gc_coef<double>(m.c, stage_row(rows + (size_t)i * GC_ROW_BYTES, bonds + 4 * GC_MAXE * GBLOCK), tb, phi[2 * i], phi[2 * i + 1], temp[i]);
+    gc_coef<double>(m.c, stage_row(rows + (size_t)i * GC_ROW_BYTES, bonds + 2 * GC_MAXE * GBLOCK), tb, phi[2 * i], phi[2 * i + 1], temp[i]);
     PhaseEval e = phase_eval(m, rho[2 * i], rho[2 * i + 1]);
     if (a) a[i] = e.a;
     if (p) p[i] = e.p();
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* 
     typedef T1<G> R;
     extern __shared__ double lds[];
     GcTable tb = stage_table(table, S, lds);
-    double* bonds = lds + gc_table_doubles(S);                       // double model: [2*MAXE dab][2*MAXE cnt] x block
-    G* gbonds = reinterpret_cast<G*>(bonds + 4 * GC_MAXE * GJBLOCK);  // dual model dab
+    double* bonds = lds + gc_table_doubles(S);                       // double model: [2*MAXE dab] x block
+    G* gbonds = reinterpret_cast<G*>(bonds + 2 * GC_MAXE * GJBLOCK);  // dual model dab
     int64_t i = (int64_t)blockIdx.x * GJBLOCK + threadIdx.x;
     if (i >= n) return;
     if (order) {  // class order of the rows (see pcs_gc_bubble_dew)
@@ -221,13 +222,12 @@ __global__ __launch_bounds__(GJBLOCK) void k_gc_jacobian(int dew, const double* 
         if (i < 0 || i >= n) return;
     }
     // (row bytes staged behind the dual model's bond area)
-    const unsigned char* row = stage_row(rows + (size_t)i * GC_ROW_BYTES, bonds + (4 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK)) * GJBLOCK);
+    const unsigned char* row = stage_row(rows + (size_t)i * GC_ROW_BYTES, bonds + (2 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK)) * GJBLOCK);
     const double T = temp[i], ph0 = phi[2 * i], ph1 = phi[2 * i + 1];
     const double4 r4 = reinterpret_cast<const double4*>(rho4)[i];  // (V0, V1, L0, L1)
     const double s0 = dew ? r4.x : r4.z, s1 = dew ? r4.y : r4.w, i0 = dew ? r4.z : r4.x, i1 = dew ? r4.w : r4.y;
     GcModelT<double> m;
     m.c.bond_dab = bonds + threadIdx.x;
-    m.c.bond_cnt = bonds + 2 * GC_MAXE * GJBLOCK + threadIdx.x;
     m.c.stride = GJBLOCK;
     gc_coef<double>(m.c, row, tb, ph0, ph1, T);
     if (agg) {
@@ -336,7 +336,7 @@ int pcs_gc_bubble_dew(int dew, const double* table, int S, const uint8_t* rows, 
     if (!table || !rows || !phi || !temp || !z || !p_init || !status) return fail_msg("pcs_gc_bubble_dew: null required pointer");
     if (reinterpret_cast<uintptr_t>(rows) & 15) return fail_msg("pcs_gc_bubble_dew: rows must be 16-byte aligned");
     const unsigned grid = (unsigned)((n + GBLOCK - 1) / GBLOCK);
-    const size_t lds = gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE + GC_ROW_LDS_DOUBLES);
+    const size_t lds = gc_lds_bytes(S, GBLOCK, 2 * GC_MAXE + GC_ROW_LDS_DOUBLES);
     hipStream_t s = as_stream(stream);
     int32_t* retry = static_cast<int32_t*>(workspace);
     if (retry) {
@@ -368,7 +368,7 @@ int pcs_gc_derivatives(const double* table, int S, const uint8_t* rows, const do
     if (!table || !rows || !phi || !temp || !rho) return fail_msg("pcs_gc_derivatives: null required pointer");
     if (reinterpret_cast<uintptr_t>(rows) & 15) return fail_msg("pcs_gc_derivatives: rows must be 16-byte aligned");
     const unsigned grid = (unsigned)((n + GBLOCK - 1) / GBLOCK);
-    hipLaunchKernelGGL(k_gc_derivatives, dim3(grid), dim3(GBLOCK), gc_lds_bytes(S, GBLOCK, 4 * GC_MAXE + GC_ROW_LDS_DOUBLES), as_stream(stream),
+    hipLaunchKernelGGL(k_gc_derivatives, dim3(grid), dim3(GBLOCK), gc_lds_bytes(S, GBLOCK, 2 * GC_MAXE + GC_ROW_LDS_DOUBLES), as_stream(stream),
                        table, S, rows, phi, temp, rho, n, a, p, mu, v);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("k_gc_derivatives launch", e);
@@ -383,8 +383,12 @@ int pcs_gc_jacobian(int dew, const double* table, int S, const uint8_t* rows, co
     if (!table || !rows || !phi || !temp || !rho4 || !jac) return fail_msg("pcs_gc_jacobian: null required pointer");
     if (reinterpret_cast<uintptr_t>(rows) & 15) return fail_msg("pcs_gc_jacobian: rows must be 16-byte aligned");
     const unsigned grid = (unsigned)((n + GJBLOCK - 1) / GJBLOCK);
-    // double model: 4*MAXE doubles per thread; dual model dab: 2*MAXE * (1 + GC_CHUNK) doubles per thread
-    const size_t lds = gc_lds_bytes(S, GJBLOCK, 4 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK) + GC_ROW_LDS_DOUBLES);
+    // double model: 2*MAXE doubles per thread; dual model dab: 2*MAXE * (1 + GC_CHUNK) doubles per thread
+    const size_t lds = gc_lds_bytes(S, GJBLOCK, 2 * GC_MAXE + 2 * GC_MAXE * (1 + GC_CHUNK) + GC_ROW_LDS_DOUBLES);
+    if (lds > 64 * 1024) {  // above the default dynamic-LDS limit
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gc_jacobian), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return fail("k_gc_jacobian attribute", ea);
+    }
     hipLaunchKernelGGL(k_gc_jacobian, dim3(grid), dim3(GJBLOCK), lds, as_stream(stream), dew, table, S, rows, phi, temp,
                        rho4, n, jac, agg, order);
     hipError_t e = hipGetLastError();

@@ -45,9 +45,10 @@ struct GcCoef {
     P na[2], nb[2];
     double isa[2];  // sign(kappa_ab eps_ab) per molecule (:317-320)
     P dij[3], S[3];
-    // bonds: per thread GC_MAXE*2 entries (dab, count) in LDS, strided by the workgroup size
+    // bonds: per thread GC_MAXE*2 diameters d_ab in LDS, strided by the workgroup size; the counts are the row's own bytes
+    // [64:80] (the kernels stage the row in LDS, gc_kernel_common.hpp::stage_row)
     P* bond_dab;
-    double* bond_cnt;
+    const unsigned char* bond_cnt;
     int stride;
 };
 
@@ -71,7 +72,7 @@ PCS_DEV P gc_diameter(const double* seg, const P& rT) { return seg[1] * (1.0 - 0
 
 // row = 80 bytes of structure (see header) -> molecule-level sums; also fills the lane's bond list (d_ab, count)
 template <class P>
-PCS_DEV void gc_mol(GcMol<P, double>& ml, P* bond_dab, double* bond_cnt, int stride, const unsigned char* row, const GcTable& tb,
+PCS_DEV void gc_mol(GcMol<P, double>& ml, P* bond_dab, int stride, const unsigned char* row, const GcTable& tb,
                     const P& rT) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -140,7 +141,6 @@ PCS_DEV void gc_mol(GcMol<P, double>& ml, P* bond_dab, double* bond_cnt, int str
         for (int e = 0; e < GC_MAXE; e++) {
             const int n = row[64 + i * GC_MAXE + e];
             const int slot = (i * GC_MAXE + e) * stride;
-            bond_cnt[slot] = (double)n;
             if (n == 0) continue;
             P da = gc_diameter<P>(tb.seg + 8 * row[32 + i * GC_MAXE + e], rT);
             P db = gc_diameter<P>(tb.seg + 8 * row[48 + i * GC_MAXE + e], rT);
@@ -230,7 +230,8 @@ template <class P>
 PCS_DEV void gc_coef(GcCoef<P>& c, const unsigned char* row, const GcTable& tb, double phi0, double phi1, const P& T) {
     P rT = d_recip(T);
     GcMol<P, double> ml;
-    gc_mol<P>(ml, c.bond_dab, c.bond_cnt, c.stride, row, tb, rT);
+    c.bond_cnt = row + 64;
+    gc_mol<P>(ml, c.bond_dab, c.stride, row, tb, rT);
     gc_finish<P, double>(c, ml, phi0, phi1, rT);
 }
 
@@ -285,7 +286,7 @@ PCS_DEV R gc_a_z(const GcCoef<P>& c, const R& r0, const R& r1, const Z& zeta3) {
 #pragma unroll 1
         for (int e = 0; e < GC_MAXE; e++) {
             const int slot = (i * GC_MAXE + e) * c.stride;
-            const double n = c.bond_cnt[slot];
+            const double n = (double)c.bond_cnt[i * GC_MAXE + e];
             if (n == 0.0) continue;
             R cd = cc * c.bond_dab[slot];
             R g = z3m1 + 3.0 * cd + 2.0 * ((cd * cd) * pk.omz);
