@@ -109,7 +109,30 @@ PCS_DEV int liquid_density_solve(const PureCoef<double>& c, double p_spec, doubl
         rho = (double)rl;
     }
 #endif
-    int st = liquid_newton(c, p_spec, tol, rho, last, false, warm);
+    int st;
+    if (__ballot(!warm) == 0ull) {
+        // every lane of the wave has its fp32 root: ONE fp64 evaluation in straight-line code (it is the last one on all
+        // but 0.04 % of the rows; as the first trip of liquid_newton's loop the same evaluation cost 0.3 ms per 1e7 rows
+        // more: the loop's live ranges spill), then the general loop for the waves in which a lane has to go on
+        const Eval e = pure_eval(c, rho);
+        bool fail = !is_finite_bits(e.dp) || !(e.dp > 0.0) || !is_finite_bits(e.p);
+        const double step = (e.p - p_spec) / e.dp;
+        const double rho_new = rho - step;
+        fail = fail || !is_finite_bits(rho_new) || !(rho_new > 0.0);
+        bool done = false;
+        if (!fail) {
+            last = e;
+            done = fabs(step) <= tol * rho;
+            rho = rho_new;
+        }
+        st = fail ? ST_FAILED : ST_OK;
+        if (__ballot(!done && !fail) != 0ull) {
+            const int st2 = liquid_newton(c, p_spec, tol, rho, last, done || fail, true);
+            if (!done && !fail) st = st2;
+        }
+    } else {
+        st = liquid_newton(c, p_spec, tol, rho, last, false, warm);
+    }
 #ifdef PCS_F32_PRESOLVE
     if (__ballot(warm && st != ST_OK) != 0ull) {
         // the fp32 root was not on the liquid branch after all: redo those lanes from the dense side
