@@ -392,7 +392,41 @@ __global__ __launch_bounds__(64, 1) void k_mix_init_queue(const double* __restri
     }
 }
 
-// K5b: robust list first, then the Newton iteration of every initialised row
+// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]; every lane of the wave must execute it
+__device__ __forceinline__ int nb_int(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ double nb_double(double x) { return __hiloint2double(nb_int(__double2hiint(x)), nb_int(__double2loint(x))); }
+// the neighbour's coefficient set, taken over by a lane that has no row of its own any more (tail of the Newton queue, below)
+__device__ __forceinline__ void adopt_neighbour_model(MixModel& m, bool take) {
+    MixCoef<double>& c = m.c;
+#define PCS_ADOPT(x) { const double t_ = nb_double(x); if (take) x = t_; }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        PCS_ADOPT(c.m[i]) PCS_ADOPT(c.mm1[i]) PCS_ADOPT(c.d[i]) PCS_ADOPT(c.na[i]) PCS_ADOPT(c.nb[i])
+#pragma unroll
+        for (int k = 0; k < 4; k++) PCS_ADOPT(c.zk[k][i])
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        PCS_ADOPT(c.A[k]) PCS_ADOPT(c.B[k]) PCS_ADOPT(c.dij[k]) PCS_ADOPT(c.S[k])
+#pragma unroll
+        for (int n = 0; n < 5; n++) PCS_ADOPT(c.pj[k][n])
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) PCS_ADOPT(c.tj[k][n])
+#undef PCS_ADOPT
+    const int pol = nb_int(c.polar ? 1 : 0), acl = nb_int(c.acls);
+    if (take) { c.polar = pol != 0; c.acls = acl; }
+}
+
+// K5b: robust list first, then the Newton iteration of every initialised row.
+// Tail: once the queue is drained the kernel ends with its longest rows -- a failing dew row runs ~20 plain + up to 24 damped
+// Newton iterations of two evaluations each, ~1 ms, while most lanes have nothing left to do (measured with all caps cut short:
+// the tails are 20 % of the bubble and 30 % of the dew kernel).  From then on a lane without a row takes over the
+// incipient-phase evaluation of its neighbour (lane ^ 1) whenever that one starts a Newton iteration: it adopts the neighbour's
+// coefficient set, evaluates at (rho_inc_1, rho_inc_2) in the same pass in which the neighbour evaluates the specified phase,
+// and hands the result over -- one pass per Newton iteration instead of two.  Same function, same inputs: identical results.
 template <bool DEW>
 __global__ __launch_bounds__(64, 1) void k_mix_bubble_dew_queue(const double* __restrict__ params,
                                                              const double* __restrict__ kij,
@@ -417,6 +451,7 @@ __global__ __launch_bounds__(64, 1) void k_mix_bubble_dew_queue(const double* __
     RowScalars r;
     r.row = 0; r.T = r.z = r.p_red = 0.0;
     int evals = 0;
+    int64_t adopted_row = -1;  // the row whose coefficient set this lane has taken over from its neighbour (tail)
     for (;;) {
         // hand rows to the lanes that have none
         unsigned long long need = __ballot(L.done());
@@ -455,11 +490,39 @@ __global__ __launch_bounds__(64, 1) void k_mix_bubble_dew_queue(const double* __
             need = __ballot(L.done());
         }
         if (__ballot(!L.done()) == 0ull) break;  // nothing in flight and nothing left to take
-        if (!L.done()) {
-            double e0, e1;
-            L.point(e0, e1);
-            PhaseEval e = phase_eval_inline(m, e0, e1);  // the only evaluation site of the kernel, inlined (see mix_solver.hpp)
+        const bool act = !L.done();
+        double e0 = 0.0, e1 = 0.0;
+        if (act) L.point(e0, e1);
+        bool help = false, helped = false;
+        if (q.drained) {  // wave-uniform: the tail (see above)
+            const bool starts_newton = act && L.stage == Lane::S_NEWTON_S;
+            // (the exchanges are executed by every lane: no short-circuit in front of them)
+            const int nb_starts = nb_int(starts_newton ? 1 : 0), nb_act = nb_int(act ? 1 : 0);
+            help = !act && nb_starts != 0;        // my neighbour starts a Newton iteration and I have no row
+            helped = starts_newton && nb_act == 0;  // ... and the other way round
+            const double h0 = nb_double(L.ri0), h1 = nb_double(L.ri1);
+            const int64_t nb_row = ((int64_t)nb_int((int)(r.row >> 32)) << 32) | (uint32_t)nb_int((int)r.row);
+            const bool adopt = help && nb_row != adopted_row;
+            if (__ballot(adopt) != 0ull) {
+                adopt_neighbour_model(m, adopt);
+                if (adopt) adopted_row = nb_row;
+            }
+            if (help) { e0 = h0; e1 = h1; }
+        }
+        PhaseEval e;
+        e.r0 = e.r1 = e.a = e.g0 = e.g1 = e.h00 = e.h01 = e.h11 = 0.0;
+        if (act || help) e = phase_eval_inline(m, e0, e1);  // the only evaluation site of the kernel, inlined (see mix_solver.hpp)
+        PhaseEval en = e;
+        if (q.drained) {
+            en.r0 = nb_double(e.r0); en.r1 = nb_double(e.r1); en.a = nb_double(e.a); en.g0 = nb_double(e.g0); en.g1 = nb_double(e.g1);
+            en.h00 = nb_double(e.h00); en.h01 = nb_double(e.h01); en.h11 = nb_double(e.h11);
+        }
+        if (act) {
             L.consume(m, e);
+            if (helped && !L.done()) {  // (stage is S_NEWTON_N now) the neighbour's evaluation of the incipient phase completes the iteration
+                L.consume(m, en);
+                evals++;
+            }
             // evaluation budget: BD_EVAL_GUARD bounds the plain form, robust_eval_budget the second attempt (mix_solver_sm.hpp)
             if (++evals >= (L.robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD) && !L.done()) L.idle();  // rc = BD_FAILED
             if (L.done() && L.rc != BD_OK && !L.robust && L.root_failed) {
