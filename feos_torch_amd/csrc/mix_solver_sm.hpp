@@ -69,6 +69,7 @@ struct BdLane {
     // damped second run of the Newton stage (see newton_failed): the start of the stage, the largest correction of the last
     // accepted iteration, the step that led to the current point, halvings of that step
     bool damped, may_damp;  // may_damp: the driver allows the damped run (set by start / start_newton; the gc kernels clear it)
+    int np_limit;           // iterations without a new smallest correction after which the Newton stage gives up (drivers may shorten it)
     int n_bt;
     double rs0, ri00, ri10, m_prev, st0, st1, st2;
     PhaseEval sv;
@@ -111,6 +112,7 @@ struct BdLane {
         resolved = false;
         rs = 0.0; ri0 = 0.0; ri1 = 0.0;
         damped = false; may_damp = true; rs0 = ri00 = ri10 = 0.0;
+        np_limit = DEW ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE;
         reset_newton();
         sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
         out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
@@ -184,6 +186,7 @@ struct BdLane {
         rc = BD_FAILED;
         rs = rs_; ri0 = ri0_; ri1 = ri1_;
         damped = false; may_damp = true;
+        np_limit = DEW ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE;
         reset_newton();
         sv.r0 = sv.r1 = sv.a = sv.g0 = sv.g1 = sv.h00 = sv.h01 = sv.h11 = 0.0;
         out.spec0 = out.spec1 = out.inc0 = out.inc1 = out.p = 0.0;
@@ -436,7 +439,7 @@ struct BdLane {
                 n_bt = 0;
             }
             if (mx < NEWTON_PROGRESS * err_best) { err_best = mx; it_best = it; }
-            else if (it - it_best >= (DEW ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE)) { newton_failed(); return; }
+            else if (it - it_best >= np_limit) { newton_failed(); return; }
             // at most a factor e per iteration -- except for a trace component of the incipient phase (mole fraction below
             // NEWTON_TRACE): its chemical potential is linear in ln rho_i there (ideal dilution), so the Newton step lands on
             // the solution however long it is and limiting it only makes the iteration march (rows with p ~ 1e-10 Pa and
@@ -547,11 +550,13 @@ constexpr int BD_EVAL_GUARD = 4 * LIQ_ROOT_MAX_IT + SS_MAX_IT * (2 * LIQ_ROOT_MA
 template <bool DEW, class Model>
 PCS_DEV int bubble_dew_solve_sm(const Model& m, double z0, double p_init, MixResult& out, int ss_max = SS_MAX_IT,
                                 int newton_max = NEWTON_MAX_IT, bool robust = false, bool* root_failed = nullptr,
-                                const double* fug = nullptr, const double* rho_pure = nullptr, bool may_damp = true) {
+                                const double* fug = nullptr, const double* rho_pure = nullptr, bool may_damp = true,
+                                int no_progress = 0) {
     BdLane<DEW> L;
     if (fug) L.start(m, z0, p_init, ss_max, newton_max, robust, fug[0], fug[1], rho_pure[0], rho_pure[1]);
     else L.start(m, z0, p_init, ss_max, newton_max, robust);
     L.may_damp = may_damp;
+    if (no_progress > 0) L.np_limit = no_progress;
     for (int guard = 0; guard < (robust ? robust_eval_budget<DEW>() : BD_EVAL_GUARD); guard++) {
         if (__ballot(!L.done()) == 0ull) break;
         if (L.done()) continue;

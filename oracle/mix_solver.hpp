@@ -206,13 +206,13 @@ struct MixSolveInfo {
 // monotonicity test (second attempt of a row whose plain iteration failed, see bubble_dew)
 template <class F, class Model>
 bool newton_stage(const Model& model, F T, const F* z, bool dew, F rs, F ri0, F ri1, F* rho_spec, F* rho_inc, MixSolveInfo& info,
-                  F tol, bool damped) {
+                  F tol, bool damped, int np_limit = 0) {
     F ri[2] = {ri0, ri1};
     const bool bt_on = damped;
     // Newton in (ln rho_spec, ln rho_inc_1, ln rho_inc_2)
     F err_prev = F(1), err_best = F(1e300);
     int it_best = 0;
-    const int no_progress = getenv("ORC_NP") ? atoi(getenv("ORC_NP")) : (dew ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE);
+    const int no_progress = getenv("ORC_NP") ? atoi(getenv("ORC_NP")) : (np_limit > 0 ? np_limit : (dew ? NEWTON_NO_PROGRESS : NEWTON_NO_PROGRESS_BUBBLE));
     F m_prev = F(1e300), st_prev[3] = {F(0), F(0), F(0)};
     int n_bt = 0;
     for (int it = 0; it < (damped ? NEWTON_DAMPED_MAX_IT : 60); it++) {
@@ -297,7 +297,7 @@ bool newton_stage(const Model& model, F T, const F* z, bool dew, F rs, F ri0, F 
 
 template <class F, class Model>
 bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, F* rho_inc, MixSolveInfo& info, F tol,
-                bool robust = false, bool may_damp = true) {
+                bool robust = false, bool may_damp = true, int np_limit = 0) {
     F z[2] = {z1, F(1) - z1};
     F rs, ri[2];  // total density of the specified phase, partial densities of the incipient one
     info.iters = 0;
@@ -466,9 +466,9 @@ bool bubble_dew(const Model& model, F T, F z1, F p_init, bool dew, F* rho_spec, 
     // Newton from there; a row whose iteration fails (it diverges or cycles from the ideal-vapour fixed point of the
     // substitution: a nearly critical liquid) gets a second, damped run from the same start (dew points)
     const F rs0 = rs, ri00 = ri[0], ri10 = ri[1];
-    if (newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, false)) return true;
+    if (newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, false, np_limit)) return true;
     static const bool damped_retry = getenv("ORC_NO_DAMPED") == nullptr;
-    if (damped_retry && may_damp && dew && !robust) return newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, true);
+    if (damped_retry && may_damp && dew && !robust) return newton_stage<F>(model, T, z, dew, rs0, ri00, ri10, rho_spec, rho_inc, info, tol, true, np_limit);
     return false;
 }
 

@@ -541,7 +541,8 @@ void gc_bd_row(GcRow& r, double T, double z, double p_pa, bool dew, F tol, doubl
     MixSolveInfo info;
     F p_red = F(p_pa) / F(T) * F(1.0 / P_UNIT);
     // (no damped second run of the Newton stage for gc rows: as csrc/gc_kernels.hip)
-    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, false, false) || (info.root_failed && bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true));
+    const int np = dew ? 10 : 0;  // GC_NO_PROGRESS_DEW of csrc/gc_kernels.hip
+    bool ok = bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, false, false, np) || (info.root_failed && bubble_dew<F>(model, F(T), F(z), p_red, dew, rs, ri, info, tol, true, false, np));
     *status = ok ? 0 : 1;
     const F* v = dew ? rs : ri;
     const F* l = dew ? ri : rs;
